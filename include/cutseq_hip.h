@@ -1,0 +1,204 @@
+/*
+ * cutseq_hip.h -- C ABI of the MI355X-native trimming engine (libcutseq_hip.so).
+ *
+ * The reference (y9c/cutseq) has no FFI: its hot path sits behind cutadapt's Python
+ * operator API.  This header is the boundary a maintainer binds
+ * with ctypes instead; every entry point names the reference interface it replaces
+ * (paths relative to the reference tree).  Plain pointers and sizes only, no
+ * exceptions, no Python/torch types.  Return value: 0 = ok, negative = cs_status;
+ * cs_last_error() gives the thread-local message.
+ *
+ * Data contract
+ *   A batch is a structure-of-arrays of reads: `seq` and `qual` are row-major byte
+ *   matrices [n_reads][stride] (ASCII as in the FASTQ record, stride a multiple of 4,
+ *   bytes past len[i] are ignored), `len` holds the read lengths (<= stride).
+ *   Headers never cross the boundary: the device returns, per read, the surviving
+ *   interval of the ORIGINAL record plus the location of the captured UMI, and the
+ *   host renames/formats (cutadapt's Renamer is string work).
+ */
+#ifndef CUTSEQ_HIP_H
+#define CUTSEQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+#define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
+#define CS_MAX_OPS 24      /* longest per-mate op chain                           */
+#define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
+
+typedef enum cs_status {
+  CS_OK = 0,
+  CS_ERR_ARG = -1,     /* bad argument (null pointer, stride, op table)      */
+  CS_ERR_HIP = -2,     /* HIP runtime error, message in cs_last_error()       */
+  CS_ERR_NO_GPU = -3,  /* no usable gfx950 device: there is NO CPU fallback   */
+  CS_ERR_NOMEM = -4,
+  CS_ERR_STATE = -5
+} cs_status;
+
+/* ---- op table: what cutseq/run.py:305-433 (single) and :493-731 (paired) compile -- */
+
+enum { CS_OP_ADAPTER = 1, CS_OP_CUT = 2, CS_OP_QTRIM = 3 };
+
+/* cutadapt aligner flags (cutadapt.align.EndSkip) */
+enum { CS_REF_START = 1, CS_QUERY_START = 2, CS_REF_END = 4, CS_QUERY_STOP = 8 };
+enum {
+  CS_WHERE_BACK = 14,               /* BackAdapter (run.py:346,569,580)              */
+  CS_WHERE_FRONT = 11,
+  CS_WHERE_PREFIX = 8,              /* PrefixAdapter (run.py:358,593,605)            */
+  CS_WHERE_SUFFIX = 2,              /* SuffixAdapter (run.py:365)                    */
+  CS_WHERE_FRONT_NOT_INTERNAL = 9,  /* NonInternalFrontAdapter (run.py:400,686,695)  */
+  CS_WHERE_BACK_NOT_INTERNAL = 6,   /* NonInternalBackAdapter (run.py:393,679,702)   */
+  CS_WHERE_ANYWHERE = 15            /* BackAdapter(force_anywhere=True)              */
+};
+enum { CS_REMOVE_BEFORE = 0, CS_REMOVE_AFTER = 1 };
+/* exact-substring short cut taken before the aligner (BackAdapter/FrontAdapter.match_to:
+ * str.find, RightmostFrontAdapter.match_to: str.rfind) */
+enum { CS_SHORTCUT_NONE = 0, CS_SHORTCUT_FIND = 1 };
+/* which candidate wins inside Aligner.locate */
+enum {
+  CS_SELECT_LEFTMOST = 0, /* cutadapt >= 4.0: first hit, replaced only by an overlapping/longer hit of higher score */
+  CS_SELECT_SCORE = 1     /* cutadapt 3.x / SURVEY.md appendix B.2: highest score, then fewest errors           */
+};
+
+/* per-read result flag bits */
+enum {
+  CS_F_ADAPTER5 = 0x01,  /* step-2 5' adapter matched (run.py:332-341, 544-563)   */
+  CS_F_ADAPTER3 = 0x02,  /* step-3 3' adapter matched (run.py:343-355, 565-590)   */
+  CS_F_INLINE = 0x04,    /* inline-barcode adapter matched (run.py:357-370)       */
+  CS_F_POLY = 0x08,      /* a poly-A/T adapter matched (run.py:388-413, 673-716)  */
+  CS_F_QTRIMMED = 0x10,  /* QualityTrimmer removed >= 1 base                      */
+  CS_F_TOO_SHORT = 0x20, /* TooShort(min_length) is true for this mate (run.py:446-451) */
+  CS_F_UNTRIMMED = 0x40  /* IsUntrimmedAny is true for this mate (run.py:97-110)  */
+};
+
+typedef struct cs_op {
+  uint8_t kind;          /* CS_OP_*                                                   */
+  uint8_t align_flags;   /* ADAPTER: CS_WHERE_*                                       */
+  uint8_t reversed;      /* ADAPTER: 1 = RightmostFrontAdapter: `seq` holds the reversed
+                            adapter, the aligner walks the read right-to-left        */
+  uint8_t remove;        /* ADAPTER: CS_REMOVE_BEFORE (read[rstop:]) / _AFTER (read[:rstart]) */
+  uint8_t shortcut;      /* ADAPTER: CS_SHORTCUT_*                                    */
+  uint8_t match_flag;    /* ADAPTER: CS_F_* bit OR-ed into the result when it matched */
+  uint8_t required;      /* ADAPTER: listed in IsUntrimmedAny -> CS_F_UNTRIMMED if it did not match */
+  uint8_t conditional;   /* CUT: ConditionalCutter semantics (run.py:145-161)         */
+  uint8_t capture;       /* CUT: 0 none, 1 = cs_result.cap_*, 2 = cs_cap2             */
+  uint8_t homopolymer;   /* ADAPTER: filled by cs_plan_create (all bases equal)       */
+  uint8_t q_base;        /* QTRIM: quality base (33)                                  */
+  uint8_t stat_slot;     /* index into cs_stats.op_matched                            */
+  uint16_t m;            /* ADAPTER: sequence length                                  */
+  uint16_t k;            /* ADAPTER: int(max_error_rate * m), computed in double on the host */
+  uint16_t min_overlap;  /* ADAPTER: already capped to m                              */
+  int16_t cut_len;       /* CUT: >0 from the 5' end, <0 from the 3' end               */
+  uint16_t force_min_len;/* CUT (conditional): force_trim_min_length                  */
+  int16_t q_cutoff;      /* QTRIM: cutoff_back (cutoff_front is 0 in cutseq)          */
+  uint8_t seq[CS_MAX_ADAPTER];     /* ADAPTER: upper-cased bases                      */
+  uint8_t thr[CS_MAX_ADAPTER + 1]; /* ADAPTER: thr[L] = floor(L * max_error_rate) in IEEE double */
+  uint8_t _pad[3];
+} cs_op;
+
+typedef struct cs_params {
+  uint32_t abi_version;  /* CS_ABI_VERSION                                   */
+  uint16_t min_length;   /* TooShort threshold (-m, run.py:943-948)           */
+  uint8_t select_rule;   /* CS_SELECT_*                                       */
+  uint8_t use_filter;    /* 1 = bit-parallel pre-filter + windowed DP (result-neutral), 0 = full DP */
+  uint32_t reserved[6];
+} cs_params;
+
+/* 8 bytes per read: [start, stop) of the ORIGINAL record survives; cap_* locates the
+ * bases a capturing cut removed (the UMI that cutseq's Renamer appends, run.py:378,643). */
+typedef struct cs_result {
+  uint16_t start;
+  uint16_t stop;
+  uint16_t cap_off;
+  uint8_t cap_len;
+  uint8_t flags;
+} cs_result;
+
+/* second capture, single-end schemes with a 5' AND a 3' UMI only (run.py:373-378) */
+typedef struct cs_cap2 {
+  uint16_t off;
+  uint8_t len;
+  uint8_t _pad;
+} cs_cap2;
+
+typedef struct cs_stats {
+  uint64_t n_reads;
+  uint64_t in_bp;
+  uint64_t out_bp;       /* sum of (stop - start) over all reads of the mate   */
+  uint64_t qualtrim_bp;  /* QualityTrimmer.trimmed_bases                       */
+  uint64_t n_too_short;
+  uint64_t n_untrimmed;
+  uint64_t n_exact_dp;   /* reads that needed the exact DP (diagnostic)        */
+  uint64_t _reserved;
+  uint64_t op_matched[CS_MAX_OPS]; /* AdapterCutter.with_adapters per op         */
+} cs_stats;
+
+/* one mate's device- or host-resident arrays */
+typedef struct cs_reads {
+  const uint8_t *seq;
+  const uint8_t *qual;
+  const uint16_t *len;
+  cs_result *out;
+  cs_cap2 *cap2; /* may be NULL */
+} cs_reads;
+
+typedef struct cs_plan cs_plan;
+typedef struct cs_engine cs_engine;
+
+int cs_abi_version(void);
+const char *cs_last_error(void);
+int cs_device_count(void); /* number of visible HIP devices, <0 on error */
+
+/* Replaces the modifier-list assembly of pipeline_single / pipeline_paired
+ * (cutseq/run.py:326-426, 533-731): the caller hands over the compiled chain per mate.
+ * n2 == 0 -> single-end.  The plan is immutable and device independent. */
+int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, const cs_params *params,
+                   cs_plan **out);
+void cs_plan_destroy(cs_plan *plan);
+
+/* One engine per GPU (one per process in the multi-GPU layout; replaces
+ * make_runner(inpaths, cores=threads), run.py:436,753). Uploads the op tables, owns a
+ * stream, the device statistics block and `n_slots` staging slots of `max_reads` reads
+ * x `max_stride` bytes for cs_trim_batch (0 slots: device-pointer API only). */
+int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t max_reads,
+                     uint32_t max_stride, cs_engine **out);
+void cs_engine_destroy(cs_engine *eng);
+
+/* The hot path, inputs already resident in HBM: ONE fused kernel launch over both mates
+ * (replaces the per-read modifier loop inside runner.run(pipeline, ...), run.py:473,794).
+ * `stream` is a hipStream_t (NULL = the engine's own stream); asynchronous.
+ * r2 == NULL for single-end. */
+int cs_trim_device(cs_engine *eng, void *stream, const cs_reads *r1, const cs_reads *r2,
+                   uint32_t n_reads, uint32_t stride);
+
+/* Same path for host buffers (pinned via cs_alloc_pinned for true overlap):
+ * hipMemcpyAsync H2D -> kernel -> hipMemcpyAsync D2H on the engine stream, using
+ * staging slot `slot`; returns immediately, cs_sync(eng, slot) waits for the results. */
+int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_reads *r2,
+                  uint32_t n_reads, uint32_t stride);
+int cs_sync(cs_engine *eng, uint32_t slot);
+
+/* Device-side counters (counterpart of cutadapt's Statistics, run.py:473,794).
+ * stats[0] = mate 1, stats[1] = mate 2.  Synchronises the engine stream. */
+int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset);
+
+/* Timing of the last cs_trim_device launch on its stream, measured with HIP events
+ * recorded around the kernel (ms).  Synchronises on the stop event. */
+int cs_last_kernel_ms(cs_engine *eng, float *ms);
+
+void *cs_alloc_pinned(size_t bytes);
+void cs_free_pinned(void *p);
+void *cs_alloc_device(int device, size_t bytes);
+void cs_free_device(int device, void *p);
+int cs_copy_to_device(int device, void *dst, const void *src, size_t bytes);
+int cs_copy_to_host(int device, void *dst, const void *src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTSEQ_HIP_H */
