@@ -1,0 +1,51 @@
+"""In-tree build of the HIP library:  python -m cutseq_amd.build  (hipcc cross-compiles gfx950 without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+SRC = HERE / "csrc" / "cutseq_hip.hip"
+DEPS = [SRC, HERE / "csrc" / "trim_kernel.hip.inc", HERE.parent / "include" / "cutseq_hip.h"]
+OUT = HERE / "libcutseq_hip.so"
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found (ROCm toolchain required)")
+    return exe
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and OUT.exists() and OUT.stat().st_mtime >= max(p.stat().st_mtime for p in DEPS):
+        return OUT
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-o", str(OUT), str(SRC)]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    env = dict(os.environ)
+    subprocess.run(cmd, check=True, cwd=str(SRC.parent), env=env)
+    return OUT
+
+
+HOST_SRC = HERE / "csrc" / "cutseq_host.c"
+HOST_OUT = HERE / "libcutseq_host.so"
+
+
+def build_host(force: bool = False) -> Path:
+    """Host-only helpers (synthetic generator): plain gcc, no GPU toolchain involved."""
+    if not force and HOST_OUT.exists() and HOST_OUT.stat().st_mtime >= HOST_SRC.stat().st_mtime:
+        return HOST_OUT
+    cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", str(HOST_OUT), str(HOST_SRC), "-lpthread"]
+    subprocess.run(cmd, check=True)
+    return HOST_OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_host(force="--force" in sys.argv))

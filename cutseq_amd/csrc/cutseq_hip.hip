@@ -1,0 +1,426 @@
+// cutseq_hip.hip -- C ABI (include/cutseq_hip.h) + launch code of the fused trimming kernel.
+// Build: hipcc -O3 --offload-arch=gfx950 -fPIC -shared -o libcutseq_hip.so cutseq_hip.hip
+// gfx950 (MI355X) only; there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/cutseq_hip.h"
+#include "trim_kernel.hip.inc"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return fail(CS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                         \
+  } while (0)
+
+constexpr uint32_t kTileRows = 256;
+constexpr uint32_t kColBytesDefault = 16 * 1024;
+constexpr uint32_t kLdsBudget = 160 * 1024;
+
+struct Slot {
+  uint8_t *d_seq[2] = {nullptr, nullptr};
+  uint8_t *d_qual[2] = {nullptr, nullptr};
+  uint16_t *d_len[2] = {nullptr, nullptr};
+  cs_result *d_out[2] = {nullptr, nullptr};
+  cs_cap2 *d_cap2 = nullptr;
+  hipEvent_t done = nullptr;
+  bool busy = false;
+};
+
+}  // namespace
+
+struct cs_plan {
+  csdev::DevPlan host;
+};
+
+struct cs_engine {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  csdev::DevPlan *d_plan = nullptr;
+  unsigned long long *d_stats = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool timed = false;
+  uint32_t max_reads = 0, max_stride = 0;
+  bool paired = false;
+  std::vector<Slot> slots;
+  uint32_t max_dynamic_lds = 0;
+};
+
+namespace {
+
+bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
+  memset(&out, 0, sizeof out);
+  out.op = in;
+  cs_op &op = out.op;
+  switch (op.kind) {
+    case CS_OP_ADAPTER: {
+      if (op.m < 1 || op.m > CS_MAX_ADAPTER) return fail(CS_ERR_ARG, "mate %d op %d: adapter length %u", mate, index, op.m);
+      if (op.min_overlap < 1 || op.min_overlap > op.m)
+        return fail(CS_ERR_ARG, "mate %d op %d: min_overlap %u not in [1, m]", mate, index, op.min_overlap);
+      if (op.align_flags > 15) return fail(CS_ERR_ARG, "mate %d op %d: bad align_flags", mate, index);
+      if (op.k > op.m || op.thr[op.m] != op.k)
+        return fail(CS_ERR_ARG, "mate %d op %d: k=%u inconsistent with thr[m]=%u", mate, index, op.k, op.thr[op.m]);
+      for (int i = 1; i <= op.m; ++i)
+        if (op.thr[i] < op.thr[i - 1] || op.thr[i] > op.thr[i - 1] + 1)
+          return fail(CS_ERR_ARG, "mate %d op %d: thr[] must be a non-decreasing unit-step table", mate, index);
+      if (op.remove > 1 || op.shortcut > 1) return fail(CS_ERR_ARG, "mate %d op %d: bad remove/shortcut", mate, index);
+      bool homo = true, acgt = true;
+      for (int i = 0; i < op.m; ++i) {
+        homo = homo && op.seq[i] == op.seq[0];
+        acgt = acgt && is_acgt(op.seq[i]);
+      }
+      op.homopolymer = homo ? 1 : 0;
+      out.base_char = op.seq[0];
+      static const char kBase[4] = {'A', 'C', 'G', 'T'};
+      for (int b = 0; b < 4; ++b) {
+        uint64_t mask = 0;
+        for (int i = 0; i < op.m && i < 64; ++i)
+          if (op.seq[i] == (uint8_t)kBase[b]) mask |= 1ull << i;
+        out.peq[b] = mask;
+      }
+      out.filter_mode = csdev::FILTER_NONE;
+      if (homo && !op.reversed && op.align_flags == CS_WHERE_BACK_NOT_INTERNAL && op.shortcut == CS_SHORTCUT_NONE)
+        out.filter_mode = csdev::FILTER_POLY_TAIL;
+      else if (homo && !op.reversed && op.align_flags == CS_WHERE_FRONT_NOT_INTERNAL &&
+               op.shortcut == CS_SHORTCUT_NONE)
+        out.filter_mode = csdev::FILTER_POLY_HEAD;
+      else if (acgt && op.m <= 32)
+        out.filter_mode = csdev::FILTER_MYERS32;
+      else if (acgt && op.m <= 64)
+        out.filter_mode = csdev::FILTER_MYERS64;
+      break;
+    }
+    case CS_OP_CUT:
+      if (op.capture > 2) return fail(CS_ERR_ARG, "mate %d op %d: capture slot %u", mate, index, op.capture);
+      if (op.capture && (op.cut_len > 255 || op.cut_len < -255))
+        return fail(CS_ERR_ARG, "mate %d op %d: capturing cuts are limited to 255 bases", mate, index);
+      break;
+    case CS_OP_QTRIM:
+      break;
+    default:
+      return fail(CS_ERR_ARG, "mate %d op %d: unknown op kind %u", mate, index, op.kind);
+  }
+  if (op.stat_slot >= CS_MAX_OPS) return fail(CS_ERR_ARG, "mate %d op %d: stat_slot out of range", mate, index);
+  return CS_OK;
+}
+
+// launch geometry for a given row stride
+struct Geometry {
+  uint32_t tile_rows, lds_stride_dw, col_dwords, lds_bytes;
+};
+
+int geometry_for(uint32_t stride, Geometry &g) {
+  if (stride == 0 || stride % 4 || stride > CS_MAX_STRIDE)
+    return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);
+  const uint32_t sdw = stride / 4;
+  g.lds_stride_dw = sdw | 1u;  // odd dword stride: conflict-free column walks
+  g.col_dwords = kColBytesDefault / 4;
+  uint32_t rows = kTileRows;
+  for (;;) {
+    const uint32_t words = rows * g.lds_stride_dw + g.col_dwords + 4 * rows + CS_MAX_OPS + csdev::kStatWords;
+    g.lds_bytes = words * 4;
+    // keep two blocks per CU resident when the rows allow it
+    if (g.lds_bytes <= kLdsBudget / 2 || rows == 64) break;
+    rows -= 64;
+  }
+  if (g.lds_bytes > kLdsBudget) return fail(CS_ERR_ARG, "stride %u does not fit the LDS tile", stride);
+  g.tile_rows = rows;
+  return CS_OK;
+}
+
+int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
+           uint32_t stride, bool time_it) {
+  Geometry g;
+  int rc = geometry_for(stride, g);
+  if (rc) return rc;
+  if (n_reads == 0) return CS_OK;
+  if ((r2 != nullptr) != eng->paired) return fail(CS_ERR_ARG, "plan is %s-end", eng->paired ? "paired" : "single");
+  csdev::KArgs a;
+  memset(&a, 0, sizeof a);
+  const cs_reads *rr[2] = {r1, r2};
+  for (int m = 0; m < (r2 ? 2 : 1); ++m) {
+    if (!rr[m]->seq || !rr[m]->qual || !rr[m]->len || !rr[m]->out) return fail(CS_ERR_ARG, "null array in mate %d", m + 1);
+    if (((uintptr_t)rr[m]->seq | (uintptr_t)rr[m]->qual) & 3) return fail(CS_ERR_ARG, "seq/qual must be 4-byte aligned");
+    a.mate[m].seq = reinterpret_cast<const uint32_t *>(rr[m]->seq);
+    a.mate[m].qual = rr[m]->qual;
+    a.mate[m].len = rr[m]->len;
+    a.mate[m].out = rr[m]->out;
+    a.mate[m].cap2 = rr[m]->cap2;
+  }
+  a.plan = eng->d_plan;
+  a.stats = eng->d_stats;
+  a.n_reads = n_reads;
+  a.stride_dw = stride / 4;
+  a.lds_stride_dw = g.lds_stride_dw;
+  a.col_dwords = g.col_dwords;
+  if (g.lds_bytes > eng->max_dynamic_lds) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    eng->max_dynamic_lds = g.lds_bytes;
+  }
+  dim3 grid((n_reads + g.tile_rows - 1) / g.tile_rows, r2 ? 2 : 1, 1);
+  dim3 block(g.tile_rows, 1, 1);
+  if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
+  hipLaunchKernelGGL(csdev::trim_kernel, grid, block, g.lds_bytes, stream, a);
+  HIP_TRY(hipGetLastError());
+  if (time_it) {
+    HIP_TRY(hipEventRecord(eng->ev_stop, stream));
+    eng->timed = true;
+  }
+  return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cs_abi_version(void) { return CS_ABI_VERSION; }
+const char *cs_last_error(void) { return g_err; }
+
+int cs_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(CS_ERR_NO_GPU, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, const cs_params *params,
+                   cs_plan **out) {
+  if (!out) return fail(CS_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!params || params->abi_version != CS_ABI_VERSION) return fail(CS_ERR_ARG, "cs_params.abi_version mismatch");
+  if (params->select_rule > CS_SELECT_SCORE) return fail(CS_ERR_ARG, "unknown select_rule");
+  if (n1 < 0 || n1 > CS_MAX_OPS || n2 < 0 || n2 > CS_MAX_OPS) return fail(CS_ERR_ARG, "op count out of range");
+  if ((n1 && !ops_r1) || (n2 && !ops_r2)) return fail(CS_ERR_ARG, "null op table");
+  cs_plan *p = new (std::nothrow) cs_plan();
+  if (!p) return fail(CS_ERR_NOMEM, "out of memory");
+  memset(&p->host, 0, sizeof p->host);
+  p->host.params = *params;
+  p->host.n_ops[0] = n1;
+  p->host.n_ops[1] = n2;
+  const cs_op *src[2] = {ops_r1, ops_r2};
+  const int cnt[2] = {n1, n2};
+  for (int m = 0; m < 2; ++m)
+    for (int i = 0; i < cnt[m]; ++i) {
+      int rc = build_dev_op(src[m][i], p->host.ops[m][i], i, m + 1);
+      if (rc) {
+        delete p;
+        return rc;
+      }
+    }
+  *out = p;
+  return CS_OK;
+}
+
+void cs_plan_destroy(cs_plan *plan) { delete plan; }
+
+void cs_engine_destroy(cs_engine *eng) {
+  if (!eng) return;
+  if (eng->device >= 0) (void)hipSetDevice(eng->device);
+  for (Slot &s : eng->slots) {
+    for (int m = 0; m < 2; ++m) {
+      if (s.d_seq[m]) (void)hipFree(s.d_seq[m]);
+      if (s.d_qual[m]) (void)hipFree(s.d_qual[m]);
+      if (s.d_len[m]) (void)hipFree(s.d_len[m]);
+      if (s.d_out[m]) (void)hipFree(s.d_out[m]);
+    }
+    if (s.d_cap2) (void)hipFree(s.d_cap2);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  if (eng->d_plan) (void)hipFree(eng->d_plan);
+  if (eng->d_stats) (void)hipFree(eng->d_stats);
+  if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
+  if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
+  if (eng->stream) (void)hipStreamDestroy(eng->stream);
+  delete eng;
+}
+
+int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t max_reads, uint32_t max_stride,
+                     cs_engine **out) {
+  if (!out) return fail(CS_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!plan) return fail(CS_ERR_ARG, "plan is null");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(CS_ERR_NO_GPU, "no HIP device visible (%s); this engine has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(CS_ERR_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CS_ERR_NO_GPU, "device %d is %s; the kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  if (n_slots) {
+    Geometry g;
+    int rc = geometry_for(max_stride, g);
+    if (rc) return rc;
+    if (!max_reads) return fail(CS_ERR_ARG, "max_reads is 0");
+  }
+  cs_engine *eng = new (std::nothrow) cs_engine();
+  if (!eng) return fail(CS_ERR_NOMEM, "out of memory");
+  eng->device = device;
+  eng->paired = plan->host.n_ops[1] > 0;
+  eng->max_reads = max_reads;
+  eng->max_stride = max_stride;
+#define ENG_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      fail(CS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      cs_engine_destroy(eng);                                                             \
+      return CS_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+  ENG_TRY(hipSetDevice(device));
+  ENG_TRY(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
+  ENG_TRY(hipEventCreate(&eng->ev_start));
+  ENG_TRY(hipEventCreate(&eng->ev_stop));
+  ENG_TRY(hipMalloc(&eng->d_plan, sizeof(csdev::DevPlan)));
+  ENG_TRY(hipMemcpy(eng->d_plan, &plan->host, sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
+  ENG_TRY(hipMalloc(&eng->d_stats, 2 * sizeof(cs_stats)));
+  ENG_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
+  eng->slots.resize(n_slots);
+  const size_t bytes = (size_t)max_reads * max_stride;
+  for (Slot &s : eng->slots) {
+    for (int m = 0; m < (eng->paired ? 2 : 1); ++m) {
+      ENG_TRY(hipMalloc(&s.d_seq[m], bytes));
+      ENG_TRY(hipMalloc(&s.d_qual[m], bytes));
+      ENG_TRY(hipMalloc(&s.d_len[m], (size_t)max_reads * sizeof(uint16_t)));
+      ENG_TRY(hipMalloc(&s.d_out[m], (size_t)max_reads * sizeof(cs_result)));
+    }
+    ENG_TRY(hipMalloc(&s.d_cap2, (size_t)max_reads * sizeof(cs_cap2)));
+    ENG_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  }
+#undef ENG_TRY
+  *out = eng;
+  return CS_OK;
+}
+
+int cs_trim_device(cs_engine *eng, void *stream, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
+                   uint32_t stride) {
+  if (!eng || !r1) return fail(CS_ERR_ARG, "null engine or reads");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t st = stream ? (hipStream_t)stream : eng->stream;
+  return launch(eng, st, r1, r2, n_reads, stride, true);
+}
+
+int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
+                  uint32_t stride) {
+  if (!eng || !r1) return fail(CS_ERR_ARG, "null engine or reads");
+  if (slot >= eng->slots.size()) return fail(CS_ERR_ARG, "slot %u out of range", slot);
+  if (n_reads > eng->max_reads || stride > eng->max_stride)
+    return fail(CS_ERR_ARG, "batch %u x %u exceeds slot capacity %u x %u", n_reads, stride, eng->max_reads, eng->max_stride);
+  if ((r2 != nullptr) != eng->paired) return fail(CS_ERR_ARG, "plan is %s-end", eng->paired ? "paired" : "single");
+  Slot &s = eng->slots[slot];
+  if (s.busy) return fail(CS_ERR_STATE, "slot %u still in flight: call cs_sync first", slot);
+  HIP_TRY(hipSetDevice(eng->device));
+  const cs_reads *rr[2] = {r1, r2};
+  cs_reads dev[2];
+  const size_t bytes = (size_t)n_reads * stride;
+  for (int m = 0; m < (r2 ? 2 : 1); ++m) {
+    if (!rr[m]->seq || !rr[m]->qual || !rr[m]->len || !rr[m]->out) return fail(CS_ERR_ARG, "null array in mate %d", m + 1);
+    HIP_TRY(hipMemcpyAsync(s.d_seq[m], rr[m]->seq, bytes, hipMemcpyHostToDevice, eng->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_qual[m], rr[m]->qual, bytes, hipMemcpyHostToDevice, eng->stream));
+    HIP_TRY(hipMemcpyAsync(s.d_len[m], rr[m]->len, (size_t)n_reads * sizeof(uint16_t), hipMemcpyHostToDevice, eng->stream));
+    dev[m].seq = s.d_seq[m];
+    dev[m].qual = s.d_qual[m];
+    dev[m].len = s.d_len[m];
+    dev[m].out = s.d_out[m];
+    dev[m].cap2 = (m == 0 && rr[m]->cap2) ? s.d_cap2 : nullptr;
+  }
+  int rc = launch(eng, eng->stream, &dev[0], r2 ? &dev[1] : nullptr, n_reads, stride, false);
+  if (rc) return rc;
+  for (int m = 0; m < (r2 ? 2 : 1); ++m) {
+    HIP_TRY(hipMemcpyAsync(rr[m]->out, s.d_out[m], (size_t)n_reads * sizeof(cs_result), hipMemcpyDeviceToHost, eng->stream));
+    if (m == 0 && rr[m]->cap2)
+      HIP_TRY(hipMemcpyAsync(rr[m]->cap2, s.d_cap2, (size_t)n_reads * sizeof(cs_cap2), hipMemcpyDeviceToHost, eng->stream));
+  }
+  HIP_TRY(hipEventRecord(s.done, eng->stream));
+  s.busy = true;
+  return CS_OK;
+}
+
+int cs_sync(cs_engine *eng, uint32_t slot) {
+  if (!eng) return fail(CS_ERR_ARG, "null engine");
+  if (slot >= eng->slots.size()) return fail(CS_ERR_ARG, "slot %u out of range", slot);
+  Slot &s = eng->slots[slot];
+  if (!s.busy) return CS_OK;
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipEventSynchronize(s.done));
+  s.busy = false;
+  return CS_OK;
+}
+
+int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset) {
+  if (!eng || !stats) return fail(CS_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(stats, eng->d_stats, 2 * sizeof(cs_stats), hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
+  return CS_OK;
+}
+
+int cs_last_kernel_ms(cs_engine *eng, float *ms) {
+  if (!eng || !ms) return fail(CS_ERR_ARG, "null argument");
+  if (!eng->timed) return fail(CS_ERR_STATE, "no timed launch yet");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipEventSynchronize(eng->ev_stop));
+  HIP_TRY(hipEventElapsedTime(ms, eng->ev_start, eng->ev_stop));
+  return CS_OK;
+}
+
+void *cs_alloc_pinned(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    fail(CS_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+void cs_free_pinned(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+void *cs_alloc_device(int device, size_t bytes) {
+  void *p = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) {
+    fail(CS_ERR_NOMEM, "hipMalloc(%zu) on device %d failed", bytes, device);
+    return nullptr;
+  }
+  return p;
+}
+void cs_free_device(int device, void *p) {
+  if (p && hipSetDevice(device) == hipSuccess) (void)hipFree(p);
+}
+int cs_copy_to_device(int device, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return CS_OK;
+}
+int cs_copy_to_host(int device, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return CS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""Batch engine: one :class:`TrimEngine` per GPU drives the fused HIP kernel.
+
+Counterpart of ``runner.run(pipeline, Progress(), outfiles)`` (cutseq/run.py:473, 794):
+where cutadapt loops over reads calling modifiers, this hands whole batches (SoA rows,
+see ``include/cutseq_hip.h``) to ``cs_trim_batch`` / ``cs_trim_device`` and gets back one
+8-byte ``cs_result`` per read.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import abi, capi
+from .plan import TrimPlan
+
+
+class TrimEngine:
+    def __init__(self, plan: TrimPlan, device: int = 0, slots: int = 2, max_reads: int = 1 << 18,
+                 max_stride: int = 152):
+        self.L = capi.load()
+        self.plan = plan
+        self.device = device
+        self._plan_h = C.c_void_p()
+        self._eng_h = C.c_void_p()
+        a1, n1, a2, n2 = plan.pack()
+        params = plan.params()
+        capi.check(self.L.cs_plan_create(C.cast(a1, C.c_void_p), n1,
+                                         C.cast(a2, C.c_void_p) if a2 is not None else None, n2,
+                                         C.byref(params), C.byref(self._plan_h)))
+        self.n_slots, self.max_reads, self.max_stride = slots, max_reads, max_stride
+        try:
+            capi.check(self.L.cs_engine_create(self._plan_h, device, slots, max_reads, max_stride,
+                                               C.byref(self._eng_h)))
+        except Exception:
+            self.L.cs_plan_destroy(self._plan_h)
+            self._plan_h = C.c_void_p()
+            raise
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_eng_h", None):
+            self.L.cs_engine_destroy(self._eng_h)
+            self._eng_h = C.c_void_p()
+        if getattr(self, "_plan_h", None):
+            self.L.cs_plan_destroy(self._plan_h)
+            self._plan_h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer path (H2D -> kernel -> D2H on the engine stream) ----------------------
+    @staticmethod
+    def _reads(seq, qual, lens, out, cap2=None) -> abi.cs_reads:
+        r = abi.cs_reads()
+        r.seq, r.qual, r.len, r.out = seq.ctypes.data, qual.ctypes.data, lens.ctypes.data, out.ctypes.data
+        r.cap2 = cap2.ctypes.data if cap2 is not None else None
+        return r
+
+    def submit(self, slot: int, seq1, qual1, len1, seq2=None, qual2=None, len2=None):
+        """Asynchronous: returns the (still being filled) result arrays; call ``wait(slot)``."""
+        n, stride = seq1.shape
+        for a in (seq1, qual1) + ((seq2, qual2) if seq2 is not None else ()):
+            assert a.dtype == np.uint8 and a.flags.c_contiguous and a.shape == (n, stride)
+        out1 = np.empty(n, dtype=abi.RESULT_DTYPE)
+        cap2 = np.empty(n, dtype=abi.CAP2_DTYPE) if self.plan.needs_cap2 else None
+        r1 = self._reads(seq1, qual1, len1, out1, cap2)
+        out2 = None
+        r2p = None
+        if seq2 is not None:
+            out2 = np.empty(n, dtype=abi.RESULT_DTYPE)
+            r2 = self._reads(seq2, qual2, len2, out2)
+            r2p = C.byref(r2)
+        capi.check(self.L.cs_trim_batch(self._eng_h, slot, C.byref(r1), r2p, n, stride))
+        return out1, cap2, out2
+
+    def wait(self, slot: int):
+        capi.check(self.L.cs_sync(self._eng_h, slot))
+
+    def trim(self, seq1, qual1, len1, seq2=None, qual2=None, len2=None, slot: int = 0):
+        """Synchronous convenience wrapper -> (res1, cap2 | None, res2 | None)."""
+        res = self.submit(slot, seq1, qual1, len1, seq2, qual2, len2)
+        self.wait(slot)
+        return res
+
+    # -- device-pointer path (inputs resident in HBM) --------------------------------------
+    def trim_device(self, r1: abi.cs_reads, r2: Optional[abi.cs_reads], n_reads: int, stride: int,
+                    stream: Optional[int] = None):
+        capi.check(self.L.cs_trim_device(self._eng_h, stream, C.byref(r1), C.byref(r2) if r2 is not None else None,
+                                         n_reads, stride))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        capi.check(self.L.cs_last_kernel_ms(self._eng_h, C.byref(ms)))
+        return float(ms.value)
+
+    def stats(self, reset: bool = False) -> Tuple[abi.cs_stats, abi.cs_stats]:
+        st = (abi.cs_stats * 2)()
+        capi.check(self.L.cs_stats_fetch(self._eng_h, C.byref(st), 1 if reset else 0))
+        return st[0], st[1]

@@ -1,0 +1,111 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, validates op tables, and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+from cutseq_amd import abi, capi, plan as planmod
+from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cutseq_amd import build
+    build.build()
+    return capi.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = (ROOT / "include" / "cutseq_hip.h").read_text()
+    declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cs_abi_version() == abi.CS_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    # compile-time truth from the C side: build a tiny probe with the same header
+    import subprocess, tempfile
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "cutseq_hip.h"
+    int main(void){
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(cs_op), offsetof(cs_op, m), offsetof(cs_op, seq),
+             offsetof(cs_op, thr), sizeof(cs_params), sizeof(cs_result), sizeof(cs_cap2), sizeof(cs_stats),
+             sizeof(cs_reads));
+      return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "p.c").write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", f"{d}/p", f"{d}/p.c"], check=True)
+        out = subprocess.run([f"{d}/p"], check=True, capture_output=True, text=True).stdout.split()
+    got = list(map(int, out))
+    want = [C.sizeof(abi.cs_op), abi.cs_op.m.offset, abi.cs_op.seq.offset, abi.cs_op.thr.offset,
+            C.sizeof(abi.cs_params), C.sizeof(abi.cs_result), C.sizeof(abi.cs_cap2), C.sizeof(abi.cs_stats),
+            C.sizeof(abi.cs_reads)]
+    assert got == want
+
+
+def _create(lib, tp):
+    a1, n1, a2, n2 = tp.pack()
+    h = C.c_void_p()
+    p = tp.params()
+    rc = lib.cs_plan_create(C.cast(a1, C.c_void_p), n1, C.cast(a2, C.c_void_p) if a2 is not None else None, n2,
+                            C.byref(p), C.byref(h))
+    return rc, h
+
+
+def test_plan_create_accepts_every_preset(lib):
+    for name, scheme in BUILDIN_ADAPTERS.items():
+        for paired in (True, False):
+            st = planmod.CutadaptConfig()
+            st.trim_polyA = True
+            st.trim_polyA_wo_direction = True
+            bc = BarcodeConfig(scheme)
+            tp = (planmod.compile_paired if paired else planmod.compile_single)(bc, st)
+            rc, h = _create(lib, tp)
+            assert rc == 0, (name, lib.cs_last_error())
+            lib.cs_plan_destroy(h)
+
+
+def test_plan_create_rejects_bad_tables(lib):
+    tp = planmod.single_adapter_plan("AGATCGGAAGAGC", 0.1)
+    a1, n1, _, _ = tp.pack()
+    p = tp.params()
+    h = C.c_void_p()
+    a1[0].min_overlap = 0
+    assert lib.cs_plan_create(C.cast(a1, C.c_void_p), n1, None, 0, C.byref(p), C.byref(h)) == abi.CS_ERR_ARG
+    assert b"min_overlap" in lib.cs_last_error()
+    a1, n1, _, _ = tp.pack()
+    a1[0].thr[5] = 3
+    assert lib.cs_plan_create(C.cast(a1, C.c_void_p), n1, None, 0, C.byref(p), C.byref(h)) == abi.CS_ERR_ARG
+    a1, n1, _, _ = tp.pack()
+    a1[0].kind = 9
+    assert lib.cs_plan_create(C.cast(a1, C.c_void_p), n1, None, 0, C.byref(p), C.byref(h)) == abi.CS_ERR_ARG
+    p.abi_version = 77
+    a1, n1, _, _ = tp.pack()
+    assert lib.cs_plan_create(C.cast(a1, C.c_void_p), n1, None, 0, C.byref(p), C.byref(h)) == abi.CS_ERR_ARG
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="GPU present: covered by the gpu suite")
+def test_engine_fails_loudly_without_gpu(lib):
+    """No GPU in the build container: the product must raise, never fall back to a CPU path."""
+    from cutseq_amd.engine import TrimEngine
+    tp = planmod.single_adapter_plan("AGATCGGAAGAGC", 0.1)
+    with pytest.raises(capi.HipUnavailable):
+        TrimEngine(tp, device=0, slots=0)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under cutseq_amd/ may reference it."""
+    for path in (ROOT / "cutseq_amd").rglob("*.py"):
+        text = path.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), path
+    for path in (ROOT / "cutseq_amd" / "csrc").iterdir():
+        assert "oracle" not in path.read_text(), path

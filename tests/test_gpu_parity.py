@@ -1,0 +1,278 @@
+"""Parity of the HIP path against the CPU oracle, bit-exact, through the C ABI.
+
+Every test here needs a real MI355X (``-m gpu``).  Results (8-byte records), second
+captures and the device statistics block must equal the oracle's on the same inputs.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from cutseq_amd import abi, hostfmt, plan as planmod, synth
+from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
+from cutseq_amd.engine import TrimEngine
+from cutseq_amd.synth import SynthBatch
+
+import util
+from test_oracle import CHAIN_CASES, WHERE
+
+pytestmark = pytest.mark.gpu
+
+
+def stats_dict(st):
+    d = st.as_dict()
+    d.pop("n_exact_dp", None)  # diagnostic: the oracle has no notion of the pre-filter
+    return d
+
+
+def run_both(tp: planmod.TrimPlan, batch: SynthBatch, threads: int = 8):
+    """-> None; asserts device == oracle for results, cap2 and stats."""
+    (o1, ocap2, ost1), m2 = util.oracle_run(tp, batch, threads=threads)
+    with TrimEngine(tp, device=0, slots=1, max_reads=max(batch.n, 1), max_stride=batch.stride) as eng:
+        g1, gcap2, g2 = eng.trim(batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2)
+        gst1, gst2 = eng.stats()
+    bad = np.nonzero(g1 != o1)[0]
+    assert bad.size == 0, (bad[:5], g1[bad[:5]], o1[bad[:5]],
+                           [util.row_bytes(batch.seq1, batch.len1, int(i)) for i in bad[:2]])
+    if ocap2 is not None:
+        assert (gcap2 == ocap2).all()
+    assert stats_dict(gst1) == stats_dict(ost1)
+    if m2 is not None:
+        o2, _, ost2 = m2
+        bad = np.nonzero(g2 != o2)[0]
+        assert bad.size == 0, (bad[:5], g2[bad[:5]], o2[bad[:5]],
+                               [util.row_bytes(batch.seq2, batch.len2, int(i)) for i in bad[:2]])
+        assert stats_dict(gst2) == stats_dict(ost2)
+    return g1, g2
+
+
+def adversarial_reads(rng: random.Random, ref: str, count: int, alpha: str, max_len: int = 70):
+    reads = []
+    for _ in range(count):
+        style = rng.random()
+        if style < 0.3:
+            s = util.random_dna(rng, rng.randint(0, max_len), alpha)
+        else:
+            core = util.mutate(rng, ref, rng.randint(0, 3), alpha)
+            cut = rng.random()
+            if cut < 0.3:
+                core = core[: rng.randint(0, len(core))]
+            elif cut < 0.6:
+                core = core[rng.randint(0, len(core)):]
+            s = util.random_dna(rng, rng.randint(0, 30), alpha) + core + util.random_dna(rng, rng.randint(0, 30), alpha)
+            if rng.random() < 0.3:
+                s += util.mutate(rng, ref, rng.randint(0, 2), alpha) + util.random_dna(rng, rng.randint(0, 8), alpha)
+        s = s[:max_len + 60]
+        reads.append((s, "I" * len(s)))
+    return reads
+
+
+def one_adapter_plan(seq, rate, min_overlap, where, remove, rightmost=False, shortcut=0, rule=0, use_filter=True):
+    op = planmod.AdapterOp("test", seq, rate, min_overlap, where, remove, rightmost=rightmost, shortcut=shortcut,
+                           match_flag=abi.CS_F_ADAPTER3)
+    return planmod.TrimPlan(r1=planmod.MateChain([op]), r2=None, has_umi=False, min_length=0,
+                            untrimmed_filter=False, select_rule=rule, use_filter=use_filter)
+
+
+@pytest.mark.parametrize("use_filter", [True, False])
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("where", sorted(WHERE))
+def test_single_adapter_all_flag_sets(where, rule, use_filter):
+    """Every cutadapt 'Where' the reference can instantiate (and ANYWHERE/FRONT), short
+    adversarial reads over small alphabets, with and without the bit-parallel pre-filter."""
+    rng = random.Random(hash((where, rule)) & 0xFFFF)
+    for trial in range(12):
+        alpha = rng.choice(["AC", "ACG", "ACGT", "ACGTN"])
+        m = rng.choice([1, 2, 3, 5, 8, 13, 20, 31, 32])
+        ref = util.random_dna(rng, m, alpha.replace("N", ""))
+        rate = rng.choice([0.0, 0.1, 0.2, 0.34])
+        mo = rng.randint(1, m)
+        remove = rng.choice([abi.CS_REMOVE_BEFORE, abi.CS_REMOVE_AFTER])
+        rightmost = rng.random() < 0.3
+        shortcut = abi.CS_SHORTCUT_FIND if rng.random() < 0.5 else abi.CS_SHORTCUT_NONE
+        tp = one_adapter_plan(ref, rate, mo, WHERE[where], remove, rightmost, shortcut, rule, use_filter)
+        batch = util.batch_from_reads(adversarial_reads(rng, ref, 700, alpha))
+        run_both(tp, batch, threads=4)
+
+
+@pytest.mark.parametrize("m", [33, 48, 64, 65, 100, 128])
+def test_long_adapters(m):
+    """m <= 64: 64-bit bit-vectors; above: no pre-filter, exact DP on every read."""
+    rng = random.Random(m)
+    ref = util.random_dna(rng, m)
+    for where, shortcut in (("BACK", 1), ("FRONT_NI", 0), ("BACK_NI", 0), ("ANYWHERE", 1), ("PREFIX", 0)):
+        tp = one_adapter_plan(ref, 0.15, 3, WHERE[where], abi.CS_REMOVE_AFTER, False, shortcut)
+        batch = util.batch_from_reads(adversarial_reads(rng, ref, 400, "ACGT", max_len=200))
+        run_both(tp, batch, threads=4)
+
+
+def test_adapter_with_non_acgt_base():
+    rng = random.Random(9)
+    ref = "ACGTNNACGTAC"
+    tp = one_adapter_plan(ref, 0.2, 3, WHERE["BACK"], abi.CS_REMOVE_AFTER, False, 1)
+    batch = util.batch_from_reads(adversarial_reads(rng, ref, 600, "ACGTN"))
+    run_both(tp, batch, threads=4)
+
+
+@pytest.mark.parametrize("base,where", [("A", "BACK_NI"), ("T", "FRONT_NI"), ("A", "BACK"), ("G", "SUFFIX")])
+@pytest.mark.parametrize("m,rate,mo", [(100, 0.15, 3), (20, 0.2, 3), (100, 0.4, 3), (8, 0.5, 5)])
+def test_homopolymer_adapters(base, where, m, rate, mo):
+    """poly-A/T ops (cutseq/run.py:388-413): mismatch-count pre-filter + windowed DP."""
+    rng = random.Random(m * 7 + len(where))
+    reads = []
+    for _ in range(1500):
+        body = util.random_dna(rng, rng.randint(0, 120))
+        run = "".join(base if rng.random() > rng.choice([0.0, 0.05, 0.2]) else rng.choice("ACGT")
+                      for _ in range(rng.choice([0, 1, 2, 3, 4, 6, 10, 25, 60, 110, 130])))
+        s = (body + run) if where in ("BACK_NI", "BACK", "SUFFIX") else (run + body)
+        if rng.random() < 0.2:
+            s = util.mutate(rng, s, 2)
+        reads.append((s, "I" * len(s)))
+    tp = one_adapter_plan(base * m, rate, mo, WHERE[where], abi.CS_REMOVE_AFTER if "BACK" in where or where == "SUFFIX"
+                          else abi.CS_REMOVE_BEFORE)
+    run_both(tp, util.batch_from_reads(reads), threads=4)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("name,flags,paired", CHAIN_CASES)
+def test_chain_presets(name, flags, paired, rule):
+    scheme = BUILDIN_ADAPTERS.get(name, name)
+    st = planmod.CutadaptConfig()
+    for k, v in flags.items():
+        setattr(st, k, v)
+    st.select_rule = rule
+    batch = synth.generate_pairs(3000, 150, scheme, seed=23, chunk_index=len(name) + rule, single_end=not paired,
+                                 poly_fraction=0.15, art5_fraction=0.05, indel_frac=0.2)
+    rng = np.random.default_rng(5)
+    for lens in (batch.len1, batch.len2):
+        if lens is None:
+            continue
+        cut = rng.random(batch.n) < 0.25
+        lens[cut] = rng.integers(0, 150, size=int(cut.sum())).astype(np.uint16)
+    tp = util.compile_plan(scheme, st, paired)
+    run_both(tp, batch)
+
+
+def test_quality_trimming_extremes():
+    rng = random.Random(4)
+    reads = []
+    for _ in range(3000):
+        n = rng.randint(0, 150)
+        s = util.random_dna(rng, n)
+        style = rng.random()
+        if style < 0.2:
+            q = "#" * n
+        elif style < 0.4:
+            q = "I" * n
+        else:
+            q = "".join(rng.choice("#-9I5!+") for _ in range(n))
+        reads.append((s, q))
+    for cutoff in (0, 20, 41):
+        tp = planmod.TrimPlan(r1=planmod.MateChain([planmod.QTrimOp(cutoff)]), r2=None, has_umi=False,
+                              min_length=20, untrimmed_filter=False)
+        run_both(tp, util.batch_from_reads(reads))
+
+
+def test_fixture_slice_byte_identical_fastq():
+    """BASELINE.json config 1 (on the 1000-pair slice of the reference's input data): the
+    FASTQ text formatted from device results equals the string-level restatement's."""
+    rec1 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R1.fq.gz")
+    rec2 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R2.fq.gz")
+    batch = util.batch_from_records(rec1, rec2)
+    names1, names2 = [r[0] for r in rec1], [r[0] for r in rec2]
+    for flags in ({}, {"trim_polyA": True}):
+        st = planmod.CutadaptConfig()
+        for k, v in flags.items():
+            setattr(st, k, v)
+        scheme = BUILDIN_ADAPTERS["TAKARAV3"]
+        tp = util.compile_plan(scheme, st, True)
+        g1, g2 = run_both(tp, batch)
+        got = util.format_batch(tp, batch, names1, names2, g1, None, g2)
+        want = util.pyref_run(scheme, st, batch, names1, names2)
+        assert got == want
+
+
+def test_edge_batches():
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], planmod.CutadaptConfig(), True)
+    # one pair, 257 pairs (tile + 1), all-empty reads
+    for n in (1, 255, 256, 257, 513):
+        b = synth.generate_pairs(n, 150, seed=n)
+        run_both(tp, b)
+    b = synth.generate_pairs(300, 150, seed=2)
+    b.len1[:] = 0
+    b.len2[:] = 0
+    run_both(tp, b)
+    # n_reads == 0 is a no-op
+    with TrimEngine(tp, device=0, slots=1, max_reads=16, max_stride=152) as eng:
+        e = np.zeros((0, 152), dtype=np.uint8)
+        l = np.zeros(0, dtype=np.uint16)
+        r1, _, r2 = eng.trim(e, e, l, e, e, l)
+        assert r1.size == 0 and r2.size == 0
+
+
+@pytest.mark.parametrize("read_len", [36, 75, 100, 151, 250, 300, 600, 1500])
+def test_read_lengths_and_strides(read_len):
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    b = synth.generate_pairs(700, read_len, seed=read_len)
+    run_both(tp, b)
+
+
+def test_config2_single_adapter_large():
+    """BASELINE.json config 2 shape (single 3' adapter AGATCGGAAGAGC, 10 % errors), 400k reads."""
+    tp = planmod.single_adapter_plan("AGATCGGAAGAGC", 0.1, 3)
+    b = synth.generate_single_adapter(400_000, 150, seed=77)
+    run_both(tp, b, threads=oracle.host_threads())
+
+
+def test_config3_full_takarav3_large_and_properties():
+    """BASELINE.json config 3 shape: TAKARAV3 + --trim-polyA, 300k pairs bit-exact against
+    the oracle, then size-independent properties on a 2M-pair batch (no oracle involved):
+    sub-interval results, statistics = sums over the records, chunk invariance."""
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    b = synth.generate_pairs(300_000, 150, seed=31)
+    run_both(tp, b, threads=oracle.host_threads())
+
+    parts = [synth.generate_pairs(250_000, 150, seed=99, chunk_index=i) for i in range(8)]
+    big = SynthBatch(*[np.concatenate([getattr(p, f) for p in parts]) for f in
+                       ("seq1", "qual1", "len1", "seq2", "qual2", "len2")])
+    with TrimEngine(tp, device=0, slots=1, max_reads=big.n, max_stride=big.stride) as eng:
+        r1, _, r2 = eng.trim(big.seq1, big.qual1, big.len1, big.seq2, big.qual2, big.len2)
+        s1, s2 = eng.stats(reset=True)
+        for r, lens, stt in ((r1, big.len1, s1), (r2, big.len2, s2)):
+            assert (r["start"] <= r["stop"]).all() and (r["stop"] <= lens).all()
+            assert stt.n_reads == big.n and stt.in_bp == int(lens.sum(dtype=np.int64))
+            assert stt.out_bp == int((r["stop"].astype(np.int64) - r["start"]).sum())
+            assert stt.n_too_short == int(((r["flags"] & abi.CS_F_TOO_SHORT) != 0).sum())
+            assert stt.op_matched[1] == int(((r["flags"] & abi.CS_F_ADAPTER3) != 0).sum())
+        # UMI capture on R2 is always the first 8 bases unless a 5' adapter was cut first
+        no5 = (r2["flags"] & abi.CS_F_ADAPTER5) == 0
+        assert (r2["cap_off"][no5] == 0).all() and (r2["cap_len"][no5] == 8).all()
+        # chunk invariance: the second half alone gives the same records
+        h = big.n // 2
+        q1, _, q2 = eng.trim(big.seq1[h:], big.qual1[h:], big.len1[h:], big.seq2[h:], big.qual2[h:], big.len2[h:])
+        assert (q1 == r1[h:]).all() and (q2 == r2[h:]).all()
+        # row permutation equivariance
+        perm = np.random.default_rng(1).permutation(h)
+        p1, _, p2 = eng.trim(np.ascontiguousarray(big.seq1[perm]), np.ascontiguousarray(big.qual1[perm]),
+                             np.ascontiguousarray(big.len1[perm]), np.ascontiguousarray(big.seq2[perm]),
+                             np.ascontiguousarray(big.qual2[perm]), np.ascontiguousarray(big.len2[perm]))
+        assert (p1 == r1[perm]).all() and (p2 == r2[perm]).all()
+
+
+def test_filter_is_result_neutral_on_large_batch():
+    """use_filter=0 (exact DP on every read, full range) == use_filter=1, GPU vs GPU."""
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    b = synth.generate_pairs(100_000, 150, seed=8, poly_fraction=0.1)
+    out = []
+    for f in (True, False):
+        tp.use_filter = f
+        with TrimEngine(tp, device=0, slots=1, max_reads=b.n, max_stride=b.stride) as eng:
+            out.append(eng.trim(b.seq1, b.qual1, b.len1, b.seq2, b.qual2, b.len2))
+    assert (out[0][0] == out[1][0]).all() and (out[0][2] == out[1][2]).all()
