@@ -127,11 +127,12 @@ def generate_pairs(n: int, read_len: int = 150, scheme: str | BarcodeConfig | No
 
 
 def generate_single_adapter(n: int, read_len: int = 150, adapter: str = "AGATCGGAAGAGC",
-                            seed: int = DEFAULT_SEED, chunk_index: int = 0) -> SynthBatch:
+                            seed: int = DEFAULT_SEED, chunk_index: int = 0, **kw) -> SynthBatch:
     """BASELINE.json config 2: single-end reads, one 3' adapter."""
     scheme = f"ACACGACGCTCTTCCGATCT>{adapter}"
-    return generate_pairs(n, read_len, scheme, seed, chunk_index, single_end=True, poly_fraction=0.0,
-                          art5_fraction=0.0)
+    kw.setdefault("poly_fraction", 0.0)
+    kw.setdefault("art5_fraction", 0.0)
+    return generate_pairs(n, read_len, scheme, seed, chunk_index, single_end=True, **kw)
 
 
 def iter_chunks(total: int, chunk: int) -> Iterator[Tuple[int, int]]:
