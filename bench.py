@@ -112,8 +112,11 @@ def main():
         r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None)
 
     eng = TrimEngine(tp, device=local_rank, slots=0)
-    stream = torch.cuda.current_stream(dev)
+    # an explicit (non-default) stream: its handle is what the C ABI launches on, and the
+    # torch events below are recorded on the same stream, so they bracket the kernel itself
+    stream = torch.cuda.Stream(device=dev)
     sh = C.c_void_p(stream.cuda_stream)
+    assert sh.value, "expected a non-null hipStream_t"
 
     def step():
         eng.trim_device(r1, r2, n, stride, stream=sh)

@@ -52,10 +52,32 @@ struct cs_plan {
   csdev::DevPlan host;
 };
 
+#include <mutex>
+namespace {
+std::mutex g_slot_mutex;
+bool g_slot_used[64][csdev::kMaxPlanSlots];  // [device][slot]
+
+int acquire_plan_slot(int device) {
+  if (device < 0 || device >= 64) return -1;
+  std::lock_guard<std::mutex> lock(g_slot_mutex);
+  for (int i = 0; i < csdev::kMaxPlanSlots; ++i)
+    if (!g_slot_used[device][i]) {
+      g_slot_used[device][i] = true;
+      return i;
+    }
+  return -1;
+}
+void release_plan_slot(int device, int slot) {
+  if (device < 0 || device >= 64 || slot < 0 || slot >= csdev::kMaxPlanSlots) return;
+  std::lock_guard<std::mutex> lock(g_slot_mutex);
+  g_slot_used[device][slot] = false;
+}
+}  // namespace
+
 struct cs_engine {
   int device = -1;
   hipStream_t stream = nullptr;
-  csdev::DevPlan *d_plan = nullptr;
+  int plan_slot = -1;  // index into the device's __constant__ plan table
   unsigned long long *d_stats = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
@@ -99,6 +121,9 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
           if (op.seq[i] == (uint8_t)kBase[b]) mask |= 1ull << i;
         out.peq[b] = mask;
       }
+      out.acgt_only = (acgt && op.m <= 64) ? 1u : 0u;
+      for (int i = 1; i <= op.m; ++i)
+        if (op.thr[i] != op.thr[i - 1]) out.thr_step[(i - 1) >> 6] |= 1ull << ((i - 1) & 63);
       out.filter_mode = csdev::FILTER_NONE;
       if (homo && !op.reversed && op.align_flags == CS_WHERE_BACK_NOT_INTERNAL && op.shortcut == CS_SHORTCUT_NONE)
         out.filter_mode = csdev::FILTER_POLY_TAIL;
@@ -168,12 +193,12 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     a.mate[m].out = rr[m]->out;
     a.mate[m].cap2 = rr[m]->cap2;
   }
-  a.plan = eng->d_plan;
   a.stats = eng->d_stats;
   a.n_reads = n_reads;
   a.stride_dw = stride / 4;
   a.lds_stride_dw = g.lds_stride_dw;
   a.col_dwords = g.col_dwords;
+  a.plan_slot = (uint32_t)eng->plan_slot;
   if (g.lds_bytes > eng->max_dynamic_lds) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
@@ -248,7 +273,7 @@ void cs_engine_destroy(cs_engine *eng) {
     if (s.d_cap2) (void)hipFree(s.d_cap2);
     if (s.done) (void)hipEventDestroy(s.done);
   }
-  if (eng->d_plan) (void)hipFree(eng->d_plan);
+  if (eng->plan_slot >= 0) release_plan_slot(eng->device, eng->plan_slot);
   if (eng->d_stats) (void)hipFree(eng->d_stats);
   if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
   if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
@@ -296,8 +321,14 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   ENG_TRY(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
   ENG_TRY(hipEventCreate(&eng->ev_start));
   ENG_TRY(hipEventCreate(&eng->ev_stop));
-  ENG_TRY(hipMalloc(&eng->d_plan, sizeof(csdev::DevPlan)));
-  ENG_TRY(hipMemcpy(eng->d_plan, &plan->host, sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
+  eng->plan_slot = acquire_plan_slot(device);
+  if (eng->plan_slot < 0) {
+    fail(CS_ERR_STATE, "more than %d live engines on device %d", csdev::kMaxPlanSlots, device);
+    cs_engine_destroy(eng);
+    return CS_ERR_STATE;
+  }
+  ENG_TRY(hipMemcpyToSymbol(HIP_SYMBOL(csdev::c_plans), &plan->host, sizeof(csdev::DevPlan),
+                            (size_t)eng->plan_slot * sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
   ENG_TRY(hipMalloc(&eng->d_stats, 2 * sizeof(cs_stats)));
   ENG_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
   eng->slots.resize(n_slots);

@@ -78,6 +78,18 @@ class SynthBatch:
         return self.seq1.shape[1]
 
 
+def usable_cpus(cap: int = 32) -> int:
+    """affinity mask capped by the cgroup CPU quota (the GPU boxes grant a share of the host)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(cap, n))
+
+
 def _stride_for(read_len: int) -> int:
     return (read_len + 3) // 4 * 4
 
@@ -116,7 +128,7 @@ def generate_pairs(n: int, read_len: int = 150, scheme: str | BarcodeConfig | No
     p.adapter_fraction, p.partial_fraction, p.poly_fraction = adapter_fraction, partial_fraction, poly_fraction
     p.art5_fraction, p.sub_rate, p.indel_frac, p.n_rate = art5_fraction, sub_rate, indel_frac, n_rate
     if threads is None:
-        threads = max(1, min(32, len(os.sched_getaffinity(0))))
+        threads = usable_cpus()
     rc = host_lib().csh_synth_pairs(
         C.byref(p), n, out.seq1.ctypes.data, out.qual1.ctypes.data, out.len1.ctypes.data,
         None if single_end else out.seq2.ctypes.data, None if single_end else out.qual2.ctypes.data,

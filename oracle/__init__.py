@@ -84,4 +84,12 @@ def trim_mate(ops, n_ops: int, params: abi.cs_params, seq: np.ndarray, qual: np.
 
 
 def host_threads() -> int:
-    return len(os.sched_getaffinity(0))
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""GPU ablation: time plan variants of the fused kernel on one resident batch (kernel-only)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np
+import torch
+
+from cutseq_amd import abi, plan as planmod, synth
+from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
+from cutseq_amd.engine import TrimEngine
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+dev = torch.device("cuda", 0)
+batch = synth.generate_pairs(n, 150)
+up = lambda a: torch.from_numpy(a).to(dev)
+d = dict(seq1=up(batch.seq1), qual1=up(batch.qual1), len1=up(batch.len1.view(np.int16)),
+         seq2=up(batch.seq2), qual2=up(batch.qual2), len2=up(batch.len2.view(np.int16)))
+out1 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+out2 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+r1 = abi.cs_reads(d["seq1"].data_ptr(), d["qual1"].data_ptr(), d["len1"].data_ptr(), out1.data_ptr(), None)
+r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None)
+bc = BarcodeConfig(BUILDIN_ADAPTERS["TAKARAV3"])
+
+
+def full(polyA=True, use_filter=True):
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = polyA
+    tp = planmod.compile_paired(bc, st)
+    tp.use_filter = use_filter
+    return tp
+
+
+def keep(tp, pred):
+    tp.r1.ops = [o for o in tp.r1.ops if pred(o)]
+    tp.r2.ops = [o for o in tp.r2.ops if pred(o)]
+    return tp
+
+
+A, Cu, Q = planmod.AdapterOp, planmod.CutOp, planmod.QTrimOp
+variants = {
+    "full": full(),
+    "full_nofilter": full(use_filter=False),
+    "no_polyA": full(polyA=False),
+    "only_5prime": keep(full(), lambda o: isinstance(o, A) and o.rightmost),
+    "only_3prime": keep(full(), lambda o: isinstance(o, A) and o.kind_name == "BackAdapter"),
+    "only_poly": keep(full(), lambda o: isinstance(o, A) and o.kind_name.startswith("NonInternal")),
+    "only_cuts": keep(full(), lambda o: isinstance(o, Cu)),
+    "only_qtrim": keep(full(), lambda o: isinstance(o, Q)),
+}
+stream = torch.cuda.Stream(device=dev)
+sh = C.c_void_p(stream.cuda_stream)
+for name, tp in variants.items():
+    eng = TrimEngine(tp, device=0, slots=0)
+    for _ in range(2):
+        eng.trim_device(r1, r2, n, batch.stride, stream=sh)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(5):
+        eng.trim_device(r1, r2, n, batch.stride, stream=sh)
+        ms.append(eng.last_kernel_ms())
+    s1, s2 = eng.stats()
+    frac = (s1.n_exact_dp + s2.n_exact_dp) / max(1, s1.n_reads + s2.n_reads)
+    t = float(np.median(ms))
+    print(f"{name:16s} {t:9.3f} ms  {n / t / 1e3:9.1f} M pairs/s  {616 * n / t / 1e6:8.1f} GB/s  exact-DP/read {frac:.3f}", flush=True)
+    eng.close()
