@@ -33,7 +33,7 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 constexpr uint32_t kTileRows = 256;
-constexpr uint32_t kColBytesDefault = 16 * 1024;
+constexpr uint32_t kColBytesPerWave = 4 * 1024;  // exact-DP column slots of one wave
 constexpr uint32_t kLdsBudget = 160 * 1024;
 
 struct Slot {
@@ -83,6 +83,7 @@ struct cs_engine {
   bool timed = false;
   uint32_t max_reads = 0, max_stride = 0;
   bool paired = false;
+  bool coded = false;
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds = 0;
 };
@@ -160,10 +161,12 @@ int geometry_for(uint32_t stride, Geometry &g) {
     return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);
   const uint32_t sdw = stride / 4;
   g.lds_stride_dw = sdw | 1u;  // odd dword stride: conflict-free column walks
-  g.col_dwords = kColBytesDefault / 4;
+  g.col_dwords = kColBytesPerWave / 4;
   uint32_t rows = kTileRows;
   for (;;) {
-    const uint32_t words = rows * g.lds_stride_dw + g.col_dwords + 4 * rows + CS_MAX_OPS + csdev::kStatWords;
+    const uint32_t waves = rows / 64;
+    const uint32_t words = rows * g.lds_stride_dw + waves * (g.col_dwords + 64 * csdev::kWaveItemDwords) +
+                           CS_MAX_OPS * (csdev::kEqTableBytes / 4) + csdev::kStatWords + 64 /* look-ahead pad */;
     g.lds_bytes = words * 4;
     // keep two blocks per CU resident when the rows allow it
     if (g.lds_bytes <= kLdsBudget / 2 || rows == 64) break;
@@ -200,14 +203,19 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
   a.col_dwords = g.col_dwords;
   a.plan_slot = (uint32_t)eng->plan_slot;
   if (g.lds_bytes > eng->max_dynamic_lds) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
     eng->max_dynamic_lds = g.lds_bytes;
   }
   dim3 grid((n_reads + g.tile_rows - 1) / g.tile_rows, r2 ? 2 : 1, 1);
   dim3 block(g.tile_rows, 1, 1);
   if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
-  hipLaunchKernelGGL(csdev::trim_kernel, grid, block, g.lds_bytes, stream, a);
+  if (eng->coded)
+    hipLaunchKernelGGL(csdev::trim_kernel<true>, grid, block, g.lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL(csdev::trim_kernel<false>, grid, block, g.lds_bytes, stream, a);
   HIP_TRY(hipGetLastError());
   if (time_it) {
     HIP_TRY(hipEventRecord(eng->ev_stop, stream));
@@ -254,6 +262,23 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
         return rc;
       }
     }
+  // coded tile: possible when every adapter base is A/C/G/T (always true for cutseq schemes)
+  bool coded = true;
+  for (int m = 0; m < 2; ++m)
+    for (int i = 0; i < cnt[m]; ++i) {
+      const cs_op &op = p->host.ops[m][i].op;
+      if (op.kind != CS_OP_ADAPTER) continue;
+      for (int j = 0; j < op.m; ++j) coded = coded && is_acgt(op.seq[j]);
+    }
+  p->host.coded = coded ? 1 : 0;
+  if (coded)
+    for (int m = 0; m < 2; ++m)
+      for (int i = 0; i < cnt[m]; ++i) {
+        csdev::DevOp &d = p->host.ops[m][i];
+        if (d.op.kind != CS_OP_ADAPTER) continue;
+        for (int j = 0; j < d.op.m; ++j) d.op.seq[j] = (uint8_t)csdev::base_code(d.op.seq[j]);
+        d.base_char = csdev::base_code(d.base_char);
+      }
   *out = p;
   return CS_OK;
 }
@@ -306,6 +331,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   if (!eng) return fail(CS_ERR_NOMEM, "out of memory");
   eng->device = device;
   eng->paired = plan->host.n_ops[1] > 0;
+  eng->coded = plan->host.coded != 0;
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
 #define ENG_TRY(expr)                                                                     \
