@@ -32,8 +32,8 @@ int fail(int code, const char *fmt, ...) {
                                       __FILE__, __LINE__);                                         \
   } while (0)
 
-constexpr uint32_t kTileRows = 256;
-constexpr uint32_t kColBytesPerWave = 4 * 1024;  // exact-DP column slots of one wave
+constexpr uint32_t kTileRows = 64;  // one wave per block: no block-level synchronisation at all
+constexpr uint32_t kColBytesPerWave = 2304;  // exact-DP scratch of one wave: 16 survivors x (32+1) rows
 constexpr uint32_t kLdsBudget = 160 * 1024;
 
 struct Slot {
@@ -162,14 +162,22 @@ int geometry_for(uint32_t stride, Geometry &g) {
   const uint32_t sdw = stride / 4;
   g.lds_stride_dw = sdw | 1u;  // odd dword stride: conflict-free column walks
   g.col_dwords = kColBytesPerWave / 4;
+  if (const char *env = getenv("CUTSEQ_COL_BYTES")) {  // tuning knob: LDS bytes of DP columns per wave
+    const long v = atol(env);
+    if (v >= 1024 && v <= 32768) g.col_dwords = (uint32_t)v / 4;
+  }
   uint32_t rows = kTileRows;
+  if (const char *env = getenv("CUTSEQ_TILE_ROWS")) {  // tuning knob: reads per block (64..256)
+    const long v = atol(env);
+    if (v == 64 || v == 128 || v == 192 || v == 256) rows = (uint32_t)v;
+  }
   for (;;) {
     const uint32_t waves = rows / 64;
     const uint32_t words = rows * g.lds_stride_dw + waves * (g.col_dwords + 64 * csdev::kWaveItemDwords) +
                            CS_MAX_OPS * (csdev::kEqTableBytes / 4) + csdev::kStatWords + 64 /* look-ahead pad */;
     g.lds_bytes = words * 4;
     // keep two blocks per CU resident when the rows allow it
-    if (g.lds_bytes <= kLdsBudget / 2 || rows == 64) break;
+    if (g.lds_bytes <= kLdsBudget / 2 || rows == 64 || getenv("CUTSEQ_COL_BYTES")) break;
     rows -= 64;
   }
   if (g.lds_bytes > kLdsBudget) return fail(CS_ERR_ARG, "stride %u does not fit the LDS tile", stride);
