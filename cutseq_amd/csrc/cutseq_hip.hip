@@ -79,11 +79,13 @@ struct cs_engine {
   hipStream_t stream = nullptr;
   int plan_slot = -1;  // index into the device's __constant__ plan table
   unsigned long long *d_stats = nullptr;
+  uint32_t *d_tile_counter = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   uint32_t max_reads = 0, max_stride = 0;
   bool paired = false;
   bool coded = false;
+  int n_cus = 256;
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds = 0;
 };
@@ -174,7 +176,7 @@ int geometry_for(uint32_t stride, Geometry &g) {
   for (;;) {
     const uint32_t waves = rows / 64;
     const uint32_t words = rows * g.lds_stride_dw + waves * (g.col_dwords + 64 * csdev::kWaveItemDwords) +
-                           CS_MAX_OPS * (csdev::kEqTableBytes / 4) + csdev::kStatWords + 64 /* look-ahead pad */;
+                           CS_MAX_OPS * (csdev::kEqTableBytes / 4) + csdev::kStatWords + 64 /* next-tile slot + look-ahead pad */;
     g.lds_bytes = words * 4;
     // keep two blocks per CU resident when the rows allow it
     if (g.lds_bytes <= kLdsBudget / 2 || rows == 64 || getenv("CUTSEQ_COL_BYTES")) break;
@@ -210,6 +212,7 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
   a.lds_stride_dw = g.lds_stride_dw;
   a.col_dwords = g.col_dwords;
   a.plan_slot = (uint32_t)eng->plan_slot;
+  a.tile_counter = eng->d_tile_counter;
   if (g.lds_bytes > eng->max_dynamic_lds) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
@@ -217,8 +220,24 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
     eng->max_dynamic_lds = g.lds_bytes;
   }
-  dim3 grid((n_reads + g.tile_rows - 1) / g.tile_rows, r2 ? 2 : 1, 1);
+  // persistent blocks: as many as stay resident (LDS-limited), each loops over its tiles
+  const uint32_t n_tiles = (n_reads + g.tile_rows - 1) / g.tile_rows;
+  uint32_t per_cu = kLdsBudget / g.lds_bytes;
+  const uint32_t wave_cap = 12 / (g.tile_rows / 64);  // 3 waves/SIMD at ~145 VGPRs
+  if (per_cu > wave_cap) per_cu = wave_cap;
+  if (per_cu < 1) per_cu = 1;
+  uint32_t resident = (uint32_t)eng->n_cus * per_cu * 2;  // 2x: late blocks even out the tail
+  const uint32_t mates = r2 ? 2 : 1;
+  uint32_t gx = resident / mates;
+  if (const char *env = getenv("CUTSEQ_GRID_X")) {
+    const long v = atol(env);
+    if (v > 0) gx = (uint32_t)v;
+  }
+  if (gx < 1) gx = 1;
+  if (gx > n_tiles) gx = n_tiles;
+  dim3 grid(gx, mates, 1);
   dim3 block(g.tile_rows, 1, 1);
+  HIP_TRY(hipMemsetAsync(eng->d_tile_counter, 0, 2 * sizeof(uint32_t), stream));
   if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
   if (eng->coded)
     hipLaunchKernelGGL(csdev::trim_kernel<true>, grid, block, g.lds_bytes, stream, a);
@@ -308,6 +327,7 @@ void cs_engine_destroy(cs_engine *eng) {
   }
   if (eng->plan_slot >= 0) release_plan_slot(eng->device, eng->plan_slot);
   if (eng->d_stats) (void)hipFree(eng->d_stats);
+  if (eng->d_tile_counter) (void)hipFree(eng->d_tile_counter);
   if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
   if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -340,6 +360,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   eng->device = device;
   eng->paired = plan->host.n_ops[1] > 0;
   eng->coded = plan->host.coded != 0;
+  eng->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
 #define ENG_TRY(expr)                                                                     \
@@ -365,6 +386,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
                             (size_t)eng->plan_slot * sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
   ENG_TRY(hipMalloc(&eng->d_stats, 2 * sizeof(cs_stats)));
   ENG_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
+  ENG_TRY(hipMalloc(&eng->d_tile_counter, 2 * sizeof(uint32_t)));
   eng->slots.resize(n_slots);
   const size_t bytes = (size_t)max_reads * max_stride;
   for (Slot &s : eng->slots) {
