@@ -33,7 +33,6 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 constexpr uint32_t kTileRows = 64;  // one wave per block: no block-level synchronisation at all
-constexpr uint32_t kColBytesPerWave = 2304;  // exact-DP scratch of one wave: 16 survivors x (32+1) rows
 constexpr uint32_t kLdsBudget = 160 * 1024;
 
 struct Slot {
@@ -85,7 +84,11 @@ struct cs_engine {
   uint32_t max_reads = 0, max_stride = 0;
   bool paired = false;
   bool coded = false;
+  bool wide = false;  // some adapter needs 64-bit bit-vectors
   int n_cus = 256;
+  uint32_t n_table_ops = 1;
+  uint32_t col_dwords = 0;   // per-wave DP scratch the plan needs
+  uint32_t waves_per_simd = 4;  // from the kernel's register count
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds = 0;
 };
@@ -158,15 +161,24 @@ struct Geometry {
   uint32_t tile_rows, lds_stride_dw, col_dwords, lds_bytes;
 };
 
-int geometry_for(uint32_t stride, Geometry &g) {
+const void *kernel_for(const cs_engine *eng) {
+  if (eng->coded)
+    return eng->wide ? reinterpret_cast<const void *>(csdev::trim_kernel<true, true>)
+                     : reinterpret_cast<const void *>(csdev::trim_kernel<true, false>);
+  return eng->wide ? reinterpret_cast<const void *>(csdev::trim_kernel<false, true>)
+                   : reinterpret_cast<const void *>(csdev::trim_kernel<false, false>);
+}
+
+int geometry_for(const cs_engine *eng, uint32_t stride, Geometry &g) {
   if (stride == 0 || stride % 4 || stride > CS_MAX_STRIDE)
     return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);
-  const uint32_t sdw = stride / 4;
-  g.lds_stride_dw = sdw | 1u;  // odd dword stride: conflict-free column walks
-  g.col_dwords = kColBytesPerWave / 4;
-  if (const char *env = getenv("CUTSEQ_COL_BYTES")) {  // tuning knob: LDS bytes of DP columns per wave
+  // coded plans keep 4 bits per base (8 per dword), raw plans the ASCII bytes; odd dword
+  // stride: conflict-free column walks
+  g.lds_stride_dw = (eng->coded ? (stride + 7) / 8 : stride / 4) | 1u;
+  g.col_dwords = eng->col_dwords;
+  if (const char *env = getenv("CUTSEQ_COL_BYTES")) {  // tuning knob: LDS bytes of DP scratch per wave
     const long v = atol(env);
-    if (v >= 1024 && v <= 32768) g.col_dwords = (uint32_t)v / 4;
+    if (v >= 1024 && v <= 32768 && (uint32_t)v / 4 > g.col_dwords) g.col_dwords = (uint32_t)v / 4;
   }
   uint32_t rows = kTileRows;
   if (const char *env = getenv("CUTSEQ_TILE_ROWS")) {  // tuning knob: reads per block (64..256)
@@ -176,10 +188,10 @@ int geometry_for(uint32_t stride, Geometry &g) {
   for (;;) {
     const uint32_t waves = rows / 64;
     const uint32_t words = rows * g.lds_stride_dw + waves * (g.col_dwords + 64 * csdev::kWaveItemDwords) +
-                           CS_MAX_OPS * (csdev::kEqTableBytes / 4) + csdev::kStatWords + 64 /* next-tile slot + look-ahead pad */;
+                           eng->n_table_ops * (csdev::kEqTableBytes / 4) + csdev::kStatWords +
+                           64 /* next-tile slot + look-ahead pad */;
     g.lds_bytes = words * 4;
-    // keep two blocks per CU resident when the rows allow it
-    if (g.lds_bytes <= kLdsBudget / 2 || rows == 64 || getenv("CUTSEQ_COL_BYTES")) break;
+    if (g.lds_bytes <= kLdsBudget || rows == 64) break;
     rows -= 64;
   }
   if (g.lds_bytes > kLdsBudget) return fail(CS_ERR_ARG, "stride %u does not fit the LDS tile", stride);
@@ -190,7 +202,7 @@ int geometry_for(uint32_t stride, Geometry &g) {
 int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
            uint32_t stride, bool time_it) {
   Geometry g;
-  int rc = geometry_for(stride, g);
+  int rc = geometry_for(eng, stride, g);
   if (rc) return rc;
   if (n_reads == 0) return CS_OK;
   if ((r2 != nullptr) != eng->paired) return fail(CS_ERR_ARG, "plan is %s-end", eng->paired ? "paired" : "single");
@@ -213,17 +225,15 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
   a.col_dwords = g.col_dwords;
   a.plan_slot = (uint32_t)eng->plan_slot;
   a.tile_counter = eng->d_tile_counter;
+  a.n_table_ops = eng->n_table_ops;
   if (g.lds_bytes > eng->max_dynamic_lds) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(csdev::trim_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    HIP_TRY(hipFuncSetAttribute(kernel_for(eng), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
     eng->max_dynamic_lds = g.lds_bytes;
   }
   // persistent blocks: as many as stay resident (LDS-limited), each loops over its tiles
   const uint32_t n_tiles = (n_reads + g.tile_rows - 1) / g.tile_rows;
   uint32_t per_cu = kLdsBudget / g.lds_bytes;
-  const uint32_t wave_cap = 12 / (g.tile_rows / 64);  // 3 waves/SIMD at ~145 VGPRs
+  const uint32_t wave_cap = (4 * eng->waves_per_simd) / (g.tile_rows / 64);
   if (per_cu > wave_cap) per_cu = wave_cap;
   if (per_cu < 1) per_cu = 1;
   uint32_t resident = (uint32_t)eng->n_cus * per_cu * 2;  // 2x: late blocks even out the tail
@@ -239,10 +249,8 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
   dim3 block(g.tile_rows, 1, 1);
   HIP_TRY(hipMemsetAsync(eng->d_tile_counter, 0, 2 * sizeof(uint32_t), stream));
   if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
-  if (eng->coded)
-    hipLaunchKernelGGL(csdev::trim_kernel<true>, grid, block, g.lds_bytes, stream, a);
-  else
-    hipLaunchKernelGGL(csdev::trim_kernel<false>, grid, block, g.lds_bytes, stream, a);
+  void *kargs[] = {&a};
+  HIP_TRY(hipLaunchKernel(kernel_for(eng), grid, block, kargs, g.lds_bytes, stream));
   HIP_TRY(hipGetLastError());
   if (time_it) {
     HIP_TRY(hipEventRecord(eng->ev_stop, stream));
@@ -350,9 +358,8 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(CS_ERR_NO_GPU, "device %d is %s; the kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
   if (n_slots) {
-    Geometry g;
-    int rc = geometry_for(max_stride, g);
-    if (rc) return rc;
+    if (max_stride == 0 || max_stride % 4 || max_stride > CS_MAX_STRIDE)
+      return fail(CS_ERR_ARG, "max_stride %u must be a multiple of 4 in [4, %d]", max_stride, CS_MAX_STRIDE);
     if (!max_reads) return fail(CS_ERR_ARG, "max_reads is 0");
   }
   cs_engine *eng = new (std::nothrow) cs_engine();
@@ -361,6 +368,19 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   eng->paired = plan->host.n_ops[1] > 0;
   eng->coded = plan->host.coded != 0;
   eng->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  eng->n_table_ops = (uint32_t)(plan->host.n_ops[0] > plan->host.n_ops[1] ? plan->host.n_ops[0] : plan->host.n_ops[1]);
+  if (eng->n_table_ops < 1) eng->n_table_ops = 1;
+  // DP scratch per wave: 16 survivors x (m+1) cells for the cooperative strips (m <= 32, ACGT),
+  // two column slots for everything that falls back to the one-lane-per-survivor DP
+  eng->col_dwords = 64;
+  for (int mt = 0; mt < 2; ++mt)
+    for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
+      const csdev::DevOp &d = plan->host.ops[mt][i];
+      if (d.op.kind != CS_OP_ADAPTER) continue;
+      if (d.filter_mode == csdev::FILTER_MYERS64) eng->wide = true;
+      const uint32_t need = (d.acgt_only && d.op.m <= 32) ? 16u * (d.op.m + 1u) : 2u * (d.op.m + 1u);
+      if (need > eng->col_dwords) eng->col_dwords = need;
+    }
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
 #define ENG_TRY(expr)                                                                     \
@@ -400,6 +420,14 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     ENG_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   }
 #undef ENG_TRY
+  {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel_for(eng)) == hipSuccess && fa.numRegs > 0) {
+      const uint32_t alloc = ((uint32_t)fa.numRegs + 7u) / 8u * 8u;
+      uint32_t w = 512u / alloc;
+      eng->waves_per_simd = w < 1 ? 1 : (w > 8 ? 8 : w);
+    }
+  }
   *out = eng;
   return CS_OK;
 }
