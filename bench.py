@@ -52,10 +52,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4_000_000, help="read pairs per step (resident batch)")
     ap.add_argument("--workload", choices=["config3", "config2"], default="config3")
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
-    ap.add_argument("--traffic-json", type=str, default=None,
-                    help="JSON with measured HBM bytes per launch from a separate rocprofv3 --pmc pass")
+    ap.add_argument("--traffic-json", type=str, default=str(ROOT / "profiles" / "r01_pmc_summary.json"),
+                    help="JSON with HBM bytes per launch measured in separate rocprofv3 --pmc passes (tools/pmc.sh)")
     return ap.parse_args()
 
 
@@ -153,8 +153,10 @@ def main():
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_per_unit * units_per_step / avg_kernel_s / 1e9
     traffic = None
-    if args.traffic_json and Path(args.traffic_json).exists():
-        traffic = json.loads(Path(args.traffic_json).read_text()).get("hbm_bytes_per_launch")
+    if paired and args.traffic_json and Path(args.traffic_json).exists():
+        pm = json.loads(Path(args.traffic_json).read_text())
+        if pm.get("pairs_per_launch") == n:  # counters were collected on this very launch shape
+            traffic = pm.get("hbm_bytes_per_launch")
 
     st1, st2 = eng.stats()
     result = {
