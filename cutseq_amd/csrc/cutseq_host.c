@@ -227,3 +227,234 @@ int csh_synth_pairs(const csh_synth_params *p, uint32_t n, uint8_t *seq1, uint8_
 }
 
 int csh_abi_version(void) { return 1; }
+
+/* ===========================================================================================
+ * FASTQ chunk parser / formatter (host side of tier E; counterpart of dnaio's reader/writer
+ * that cutadapt drives for the reference, cutseq/run.py:434-441, 751-758).  String work only.
+ * =========================================================================================== */
+
+/* Count complete 4-line records at the start of buf (at most max_records).
+ * Returns the number of records; *consumed = bytes they occupy, *max_len = longest sequence line.
+ * A record is complete when its 4th line ends with '\n' or (at_eof) at the end of the buffer. */
+int64_t csh_fastq_count(const uint8_t *buf, int64_t n, int64_t max_records, int at_eof, int64_t *consumed,
+                        int32_t *max_len) {
+  int64_t pos = 0, rec = 0, rec_start = 0;
+  int32_t longest = 0;
+  while (rec < max_records && pos < n) {
+    int64_t p = pos;
+    int32_t seq_len = 0;
+    int ok = 1;
+    for (int line = 0; line < 4; line++) {
+      const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', (size_t)(n - p));
+      int64_t end;
+      if (nl) {
+        end = nl - buf;
+      } else if (at_eof && line == 3 && p < n) {
+        end = n; /* last line without trailing newline */
+      } else {
+        ok = 0;
+        break;
+      }
+      if (line == 1) {
+        int64_t l = end - p;
+        if (l > 0 && buf[end - 1] == '\r') l--;
+        seq_len = (int32_t)l;
+      }
+      p = nl ? end + 1 : end;
+    }
+    if (!ok) break;
+    if (seq_len > longest) longest = seq_len;
+    rec++;
+    pos = p;
+    rec_start = pos;
+  }
+  *consumed = rec_start;
+  *max_len = longest;
+  return rec;
+}
+
+/* Parse exactly n_records records into SoA rows.  name_off/name_len locate the header (without
+ * '@', without line end) inside buf.  Returns bytes consumed, or -(record index + 1) on a
+ * malformed record (missing '@' / '+', sequence and quality lengths differ, longer than stride). */
+int64_t csh_fastq_parse(const uint8_t *buf, int64_t n, int64_t n_records, uint32_t stride, uint8_t *seq,
+                        uint8_t *qual, uint16_t *len, int64_t *name_off, int32_t *name_len) {
+  int64_t pos = 0;
+  for (int64_t r = 0; r < n_records; r++) {
+    int64_t starts[4], ends[4];
+    for (int line = 0; line < 4; line++) {
+      if (pos > n) return -(r + 1);
+      const uint8_t *nl = pos < n ? (const uint8_t *)memchr(buf + pos, '\n', (size_t)(n - pos)) : NULL;
+      int64_t end = nl ? (nl - buf) : n;
+      starts[line] = pos;
+      ends[line] = end;
+      if (ends[line] > starts[line] && buf[ends[line] - 1] == '\r') ends[line]--;
+      pos = nl ? end + 1 : end;
+    }
+    if (ends[0] <= starts[0] || buf[starts[0]] != '@') return -(r + 1);
+    if (ends[2] <= starts[2] || buf[starts[2]] != '+') return -(r + 1);
+    int64_t sl = ends[1] - starts[1], ql = ends[3] - starts[3];
+    if (sl != ql || sl > (int64_t)stride || sl > 65535) return -(r + 1);
+    uint8_t *srow = seq + (size_t)r * stride, *qrow = qual + (size_t)r * stride;
+    memcpy(srow, buf + starts[1], (size_t)sl);
+    memcpy(qrow, buf + starts[3], (size_t)sl);
+    if ((uint32_t)sl < stride) {
+      memset(srow + sl, 0, stride - (size_t)sl);
+      memset(qrow + sl, 0, stride - (size_t)sl);
+    }
+    len[r] = (uint16_t)sl;
+    name_off[r] = starts[0] + 1;
+    name_len[r] = (int32_t)(ends[0] - starts[0] - 1);
+  }
+  return pos;
+}
+
+typedef struct csh_result {
+  uint16_t start, stop, cap_off;
+  uint8_t cap_len, flags;
+} csh_result;
+typedef struct csh_cap2 {
+  uint16_t off;
+  uint8_t len, pad;
+} csh_cap2;
+
+typedef struct csh_format_params {
+  int32_t paired;
+  int32_t has_umi;          /* Renamer template carries the captured bases */
+  int32_t untrimmed_filter; /* IsUntrimmedAny filter installed */
+  int32_t reverse_complement; /* single-end --auto-rc on a '-' library */
+  uint8_t flag_too_short, flag_untrimmed, pad[2];
+  const char *suffix1[2]; /* SuffixRemover literals of mate 1, applied in order */
+  const char *suffix2[2];
+} csh_format_params;
+
+static int is_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+/* SuffixRemover chain on the whole header */
+static int32_t strip_suffixes(const uint8_t *name, int32_t n, const char *const suf[2]) {
+  for (int i = 0; i < 2; i++) {
+    if (!suf[i]) continue;
+    int32_t sl = (int32_t)strlen(suf[i]);
+    if (sl && n >= sl && memcmp(name + n - sl, suf[i], (size_t)sl) == 0) n -= sl;
+  }
+  return n;
+}
+/* Renamer.parse_name: name.split(maxsplit=1)[0] if there are two fields, else the whole name */
+static void read_id(const uint8_t *name, int32_t n, int32_t *off, int32_t *len) {
+  int32_t a = 0;
+  while (a < n && is_space(name[a])) a++;
+  int32_t b = a;
+  while (b < n && !is_space(name[b])) b++;
+  int32_t c = b;
+  while (c < n && is_space(name[c])) c++;
+  if (b > a && c < n) { /* two fields */
+    *off = a;
+    *len = b - a;
+  } else {
+    *off = 0;
+    *len = n;
+  }
+}
+/* dnaio.record_names_match: ids up to the first space/tab, a trailing 1/2/3 ignored */
+static int ids_match(const uint8_t *n1, int32_t l1, const uint8_t *n2, int32_t l2) {
+  int32_t a = 0, b = 0;
+  while (a < l1 && n1[a] != ' ' && n1[a] != '\t') a++;
+  while (b < l2 && n2[b] != ' ' && n2[b] != '\t') b++;
+  if (a && b && n1[a - 1] >= '1' && n1[a - 1] <= '3' && n2[b - 1] >= '1' && n2[b - 1] <= '3') {
+    a--;
+    b--;
+  }
+  return a == b && memcmp(n1, n2, (size_t)a) == 0;
+}
+
+static uint8_t rc_table[256];
+static int rc_ready = 0;
+static void rc_init(void) {
+  for (int i = 0; i < 256; i++) rc_table[i] = (uint8_t)i;
+  const char *from = "ACGTUMRWSYKVHDBNacgtumrwsykvhdbn", *to = "TGCAAKYWSRMBDHVNtgcaakywsrmbdhvn";
+  for (int i = 0; from[i]; i++) rc_table[(uint8_t)from[i]] = (uint8_t)to[i];
+  rc_ready = 1;
+}
+
+static uint8_t *emit(uint8_t *o, const uint8_t *id, int32_t idl, const uint8_t *tag1, int32_t t1, const uint8_t *tag2,
+                     int32_t t2, int has_umi, const uint8_t *seq, const uint8_t *qual, int32_t s, int32_t e, int rc) {
+  *o++ = '@';
+  memcpy(o, id, (size_t)idl);
+  o += idl;
+  if (has_umi) {
+    *o++ = '_';
+    memcpy(o, tag1, (size_t)t1);
+    o += t1;
+    memcpy(o, tag2, (size_t)t2);
+    o += t2;
+  }
+  *o++ = '\n';
+  int32_t L = e - s;
+  if (!rc) {
+    memcpy(o, seq + s, (size_t)L);
+    o += L;
+    *o++ = '\n';
+    *o++ = '+';
+    *o++ = '\n';
+    memcpy(o, qual + s, (size_t)L);
+    o += L;
+  } else {
+    for (int32_t i = 0; i < L; i++) *o++ = rc_table[seq[e - 1 - i]];
+    *o++ = '\n';
+    *o++ = '+';
+    *o++ = '\n';
+    for (int32_t i = 0; i < L; i++) *o++ = qual[e - 1 - i];
+  }
+  *o++ = '\n';
+  return o;
+}
+
+/* Format one chunk.  out[route][mate] are caller-allocated buffers (capacity: raw chunk bytes +
+ * 260 per record is always enough); out_len[route][mate] receives the bytes written and
+ * counts[route] the records (pairs).  Routes: 0 trimmed, 1 short, 2 untrimmed.
+ * Returns 0, or -(record index + 1) when the mates' ids differ. */
+int64_t csh_format_chunk(const csh_format_params *fp, int64_t n, uint32_t stride, const uint8_t *raw1,
+                         const int64_t *name_off1, const int32_t *name_len1, const uint8_t *seq1,
+                         const uint8_t *qual1, const csh_result *res1, const csh_cap2 *cap2, const uint8_t *raw2,
+                         const int64_t *name_off2, const int32_t *name_len2, const uint8_t *seq2,
+                         const uint8_t *qual2, const csh_result *res2, uint8_t *out[3][2], int64_t out_len[3][2],
+                         int64_t counts[3]) {
+  if (!rc_ready) rc_init();
+  uint8_t *w[3][2];
+  for (int r = 0; r < 3; r++) {
+    counts[r] = 0;
+    for (int m = 0; m < 2; m++) w[r][m] = out[r][m];
+  }
+  for (int64_t i = 0; i < n; i++) {
+    const uint8_t *nm1 = raw1 + name_off1[i];
+    int32_t nl1 = strip_suffixes(nm1, name_len1[i], fp->suffix1);
+    int32_t id1o, id1l;
+    read_id(nm1, nl1, &id1o, &id1l);
+    const uint8_t *s1 = seq1 + (size_t)i * stride, *q1 = qual1 + (size_t)i * stride;
+    unsigned flags = res1[i].flags;
+    if (!fp->paired) {
+      int route = (flags & fp->flag_too_short) ? 1 : ((fp->untrimmed_filter && (flags & fp->flag_untrimmed)) ? 2 : 0);
+      const uint8_t *t2 = cap2 ? s1 + cap2[i].off : NULL;
+      w[route][0] = emit(w[route][0], nm1 + id1o, id1l, s1 + res1[i].cap_off, res1[i].cap_len, t2,
+                         cap2 ? cap2[i].len : 0, fp->has_umi, s1, q1, res1[i].start, res1[i].stop,
+                         fp->reverse_complement);
+      counts[route]++;
+      continue;
+    }
+    const uint8_t *nm2 = raw2 + name_off2[i];
+    int32_t nl2 = strip_suffixes(nm2, name_len2[i], fp->suffix2);
+    if (!ids_match(nm1, nl1, nm2, nl2)) return -(i + 1);
+    int32_t id2o, id2l;
+    read_id(nm2, nl2, &id2o, &id2l);
+    const uint8_t *s2 = seq2 + (size_t)i * stride, *q2 = qual2 + (size_t)i * stride;
+    flags |= res2[i].flags;
+    int route = (flags & fp->flag_too_short) ? 1 : ((fp->untrimmed_filter && (flags & fp->flag_untrimmed)) ? 2 : 0);
+    w[route][0] = emit(w[route][0], nm1 + id1o, id1l, s1 + res1[i].cap_off, res1[i].cap_len, s2 + res2[i].cap_off,
+                       res2[i].cap_len, fp->has_umi, s1, q1, res1[i].start, res1[i].stop, 0);
+    w[route][1] = emit(w[route][1], nm2 + id2o, id2l, s1 + res1[i].cap_off, res1[i].cap_len, s2 + res2[i].cap_off,
+                       res2[i].cap_len, fp->has_umi, s2, q2, res2[i].start, res2[i].stop, 0);
+    counts[route]++;
+  }
+  for (int r = 0; r < 3; r++)
+    for (int m = 0; m < 2; m++) out_len[r][m] = w[r][m] - out[r][m];
+  return 0;
+}

@@ -1,0 +1,182 @@
+"""Host side of the CLI (no GPU): native FASTQ parser / formatter against the Python record logic,
+chunking, error behaviour, and the argument handling the reference's main() performs."""
+import contextlib
+import gzip
+import io
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from cutseq_amd import abi, fastq, hostfmt, plan as planmod, run as cli
+from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
+
+import util
+
+
+def write_fq(path, records, gz=True, eol=b"\n", final_newline=True):
+    body = b"".join(b"@" + n + eol + s + eol + b"+" + eol + q + eol for n, s, q in records)
+    if not final_newline:
+        body = body[: -len(eol)]
+    if gz:
+        with gzip.open(path, "wb") as fh:
+            fh.write(body)
+    else:
+        Path(path).write_bytes(body)
+    return path
+
+
+def test_chunks_roundtrip_fixture(tmp_path):
+    rec1 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R1.fq.gz")
+    rec2 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R2.fq.gz")
+    chunks = list(fastq.read_chunks(str(util.GOLDEN / "fixture1k_R1.fq.gz"), str(util.GOLDEN / "fixture1k_R2.fq.gz"),
+                                    chunk_reads=300))
+    assert [c.n for c in chunks] == [300, 300, 300, 100]
+    i = 0
+    for c in chunks:
+        assert c.stride == 160 and c.paired
+        for j in range(c.n):
+            name = c.raw1[c.name_off1[j]: c.name_off1[j] + c.name_len1[j]]
+            assert (name, util.row_bytes(c.seq1, c.len1, j), util.row_bytes(c.qual1, c.len1, j)) == rec1[i]
+            name2 = c.raw2[c.name_off2[j]: c.name_off2[j] + c.name_len2[j]]
+            assert (name2, util.row_bytes(c.seq2, c.len2, j), util.row_bytes(c.qual2, c.len2, j)) == rec2[i]
+            i += 1
+    assert i == 1000
+
+
+@pytest.mark.parametrize("eol,final_newline,gz", [(b"\n", True, True), (b"\r\n", True, False), (b"\n", False, False)])
+def test_parser_line_endings(tmp_path, eol, final_newline, gz):
+    recs = [(b"r1 c", b"ACGTN", b"IIII#"), (b"r2", b"", b""), (b"r3/1", b"GG", b"#I")]
+    p = write_fq(tmp_path / "a.fq", recs, gz=gz, eol=eol, final_newline=final_newline)
+    (c,) = list(fastq.read_chunks(str(p)))
+    assert c.n == 3 and list(c.len1) == [5, 0, 2]
+    assert c.raw1[c.name_off1[2]: c.name_off1[2] + c.name_len1[2]] == b"r3/1"
+
+
+def test_parser_errors(tmp_path):
+    p = tmp_path / "bad.fq"
+    p.write_bytes(b"@r1\nACGT\n+\nIII\n")  # quality shorter than sequence
+    with pytest.raises(fastq.FastqFormatError):
+        list(fastq.read_chunks(str(p)))
+    p.write_bytes(b"r1\nACGT\n+\nIIII\n")  # no '@'
+    with pytest.raises(fastq.FastqFormatError):
+        list(fastq.read_chunks(str(p)))
+    p.write_bytes(b"@r1\nACGT\n+\nIIII\n@r2\nAC\n")  # truncated last record
+    with pytest.raises(fastq.FastqFormatError):
+        list(fastq.read_chunks(str(p)))
+    a = write_fq(tmp_path / "a.fq", [(b"x", b"A", b"I"), (b"y", b"C", b"I")], gz=False)
+    b = write_fq(tmp_path / "b.fq", [(b"x", b"A", b"I")], gz=False)
+    with pytest.raises(fastq.FastqFormatError):  # more reads in one file than in the other
+        list(fastq.read_chunks(str(a), str(b)))
+
+
+@pytest.mark.parametrize("preset,flags,paired", [
+    ("TAKARAV3", {"trim_polyA": True}, True),
+    ("SACSEQV3", {}, False),
+    ("INLINE", {"ensure_inline_barcode": True}, True),
+    ("TAKARAV3", {"auto_rc": True}, False),
+])
+def test_native_formatter_equals_python_record_logic(preset, flags, paired):
+    """csh_format_chunk == hostfmt.format_pair/format_single, results taken from the oracle."""
+    scheme = BUILDIN_ADAPTERS[preset]
+    st = planmod.CutadaptConfig()
+    for k, v in flags.items():
+        setattr(st, k, v)
+    tp = util.compile_plan(scheme, st, paired)
+    rec1 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R1.fq.gz")
+    rec2 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R2.fq.gz")
+    rec1[3] = (b"weird/1", rec1[3][1], rec1[3][2])
+    rec2[3] = (b"weird/2", rec2[3][1], rec2[3][2])
+    rec1[4] = (b"tab\tcomment.1", rec1[4][1], rec1[4][2])
+    rec2[4] = (b"tab\tcomment.2", rec2[4][1], rec2[4][2])
+    chunks = list(fastq.read_chunks(str(util.GOLDEN / "fixture1k_R1.fq.gz"),
+                                    str(util.GOLDEN / "fixture1k_R2.fq.gz") if paired else None))
+    (c,) = chunks
+    # patch the names in the raw buffers through a rebuilt chunk
+    body1 = b"".join(b"@" + n + b"\n" + s + b"\n+\n" + q + b"\n" for n, s, q in rec1)
+    body2 = b"".join(b"@" + n + b"\n" + s + b"\n+\n" + q + b"\n" for n, s, q in rec2)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        Path(d, "1.fq").write_bytes(body1)
+        Path(d, "2.fq").write_bytes(body2)
+        (c,) = list(fastq.read_chunks(str(Path(d, "1.fq")), str(Path(d, "2.fq")) if paired else None))
+    batch = util.batch_from_records(rec1, rec2 if paired else None)
+    (r1, cap2, _), m2 = util.oracle_run(tp, batch)
+    r2 = m2[0] if m2 else None
+    # same stride as the chunk (batch_from_records pads to a multiple of 4 as well)
+    data, counts = fastq.format_chunk(c, tp, r1, cap2, r2)
+    want = util.format_batch(tp, batch, [r[0] for r in rec1], [r[0] for r in rec2], r1, cap2, r2)
+    for route in range(3):
+        w1 = b"".join(x[1] for x in want if x[0] == route)
+        assert data[route][0] == w1
+        if paired:
+            assert data[route][1] == b"".join(x[2] for x in want if x[0] == route)
+        assert counts[route] == sum(1 for x in want if x[0] == route)
+
+
+def test_mismatched_pair_ids_raise():
+    st = planmod.CutadaptConfig()
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        write_fq(Path(d, "1.fq"), [(b"a 1", b"ACGT" * 10, b"I" * 40)], gz=False)
+        write_fq(Path(d, "2.fq"), [(b"b 2", b"ACGT" * 10, b"I" * 40)], gz=False)
+        (c,) = list(fastq.read_chunks(str(Path(d, "1.fq")), str(Path(d, "2.fq"))))
+    res = np.zeros(1, dtype=abi.RESULT_DTYPE)
+    with pytest.raises(ValueError, match="Input read IDs not identical"):
+        fastq.format_chunk(c, tp, res, None, res.copy())
+
+
+# ---------------------------------------------------------------- CLI argument handling (reference main())
+
+
+def parse(argv):
+    return cli.resolve_args(cli.build_parser().parse_args(argv))
+
+
+def test_cli_output_naming_and_preset_resolution():
+    a = parse(["-A", "takarav3", "x/sample_R1_001.fastq.gz", "x/sample_R2_001.fastq.gz"])
+    assert a.adapter_scheme == BUILDIN_ADAPTERS["TAKARAV3"]
+    assert a.output_file == ["x/sample_trimmed_R1.fastq.gz", "x/sample_trimmed_R2.fastq.gz"]
+    assert a.short_file == ["x/sample_short_R1.fastq.gz", "x/sample_short_R2.fastq.gz"]
+    assert a.untrimmed_file == [None, None]
+    a = parse(["-a", "acgt acgt > tttt", "-O", "out/p", "in.fq"])
+    assert a.adapter_scheme == "ACGTACGT>TTTT"
+    assert a.output_file == ["out/p_trimmed_R1.fastq.gz"] and a.short_file == ["out/p_short_R1.fastq.gz"]
+    a = parse(["-A", "INLINE", "--ensure-inline-barcode", "a_R1.fq.gz", "a_R2.fq.gz"])
+    assert a.untrimmed_file == ["a_untrimmed_R1.fastq.gz", "a_untrimmed_R2.fastq.gz"]
+    a = parse(["-A", "TAKARAV3", "--ensure-inline-barcode", "a_R1.fq.gz", "a_R2.fq.gz"])
+    assert a.untrimmed_file == [None, None]  # scheme has no inline barcode
+    a = parse(["-A", "AAAA>CCCC", "r.fq"])  # unknown preset name is reused as the scheme
+    assert a.adapter_scheme == "AAAA>CCCC"
+    a = parse(["-A", "TAKARAV3", "-a", "AAAA>CCCC", "r.fq"])  # explicit scheme wins
+    assert a.adapter_scheme == "AAAA>CCCC"
+
+
+def test_cli_error_exits():
+    for argv in (["a", "b", "c", "-A", "TAKARAV3"], ["r.fq"], ["-A", "TAKARAV3", "-o", "only_one.fq", "a.fq", "b.fq"],
+                 ["-A", "TAKARAV3"]):
+        with pytest.raises(SystemExit) as e:
+            parse(argv)
+        assert e.value.code == 1, argv
+    with pytest.raises(SystemExit) as e:  # invalid scheme -> BarcodeConfig exits 1
+        cli.main(["-a", "AAAAXN>CCCC", "-n", "r.fq"])
+    assert e.value.code == 1
+    with pytest.raises(SystemExit) as e:
+        cli.main([])
+    assert e.value.code == 0
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), pytest.raises(SystemExit) as e:
+        cli.main(["--list-adapters"])
+    assert e.value.code == 0 and "TAKARAV3" in buf.getvalue()
+
+
+def test_cli_dry_run_lists_the_chain(capsys):
+    cli.main(["-A", "TAKARAV3", "--trim-polyA", "-n", "r_R1.fq.gz"])
+    out = capsys.readouterr().out
+    assert "Step 1: SuffixRemover('.1')" in out and "RightmostFrontAdapter" in out
+    assert "QualityTrimmer(cutoff_front=0, cutoff_back=20" in out and "Renamer" in out
+    cli.main(["-A", "TAKARAV3", "-n", "r_R1.fq.gz", "r_R2.fq.gz"])
+    out = capsys.readouterr().out
+    assert "p5: ACACGACGCTCTTCCGATCT (AGATCGGAAGAGCGTCGTGT)" in out and "strand: -" in out
