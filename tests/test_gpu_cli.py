@@ -55,7 +55,7 @@ def test_cli_paired_takarav3(tmp_path, capsys):
 def test_cli_paired_auto_rc_swaps_outputs(tmp_path):
     o1, o2 = str(tmp_path / "a.fq"), str(tmp_path / "b.fq")  # plain (no .gz): written uncompressed
     s1, s2 = str(tmp_path / "s1.fq.gz"), str(tmp_path / "s2.fq.gz")
-    cli.main(["-A", "TAKARAV3", "--auto-rc", "-o", o1, o2, "-s", s1, s2, R1, R2])
+    cli.main([R1, R2, "-A", "TAKARAV3", "--auto-rc", "-o", o1, o2, "-s", s1, s2])  # positionals first: -s is nargs="+"
     want = expected(BUILDIN_ADAPTERS["TAKARAV3"], {"auto_rc": True}, True)
     assert open(o1, "rb").read() == want["trimmed"][1]  # '-' strand library: R2 goes to the first file
     assert open(o2, "rb").read() == want["trimmed"][0]
@@ -65,7 +65,7 @@ def test_cli_paired_auto_rc_swaps_outputs(tmp_path):
 def test_cli_single_end_rc_and_untrimmed(tmp_path):
     out, short, untr = (str(tmp_path / f"{n}.fastq.gz") for n in ("o", "s", "u"))
     scheme = "ACACGACGCTCTTCCGATCT(GGG)NNN<XXXAGATCGGAAGAGCACACGTC"
-    cli.main(["-a", scheme, "--auto-rc", "--ensure-inline-barcode", "--trim-polyA", "-o", out, "-s", short, "-u", untr, R1])
+    cli.main([R1, "-a", scheme, "--auto-rc", "--ensure-inline-barcode", "--trim-polyA", "-o", out, "-s", short, "-u", untr])
     want = expected(scheme, {"auto_rc": True, "ensure_inline_barcode": True, "trim_polyA": True}, False, True)
     assert gunzip(out) == want["trimmed"][0]
     assert gunzip(short) == want["short"][0]
