@@ -38,15 +38,17 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    import os
+    lib_path = Path(os.environ.get("CUTSEQ_HIP_LIB", str(LIB_PATH)))  # A/B builds when tuning
+    if not lib_path.exists():
         raise HipUnavailable(
-            f"{LIB_PATH} not found: build it with `python -m cutseq_amd.build` "
+            f"{lib_path} not found: build it with `python -m cutseq_amd.build` "
             "(hipcc --offload-arch=gfx950). cutseq_amd has no CPU trimming path."
         )
     try:
-        L = C.CDLL(str(LIB_PATH))
+        L = C.CDLL(str(lib_path))
     except OSError as exc:  # pragma: no cover
-        raise HipUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+        raise HipUnavailable(f"cannot load {lib_path}: {exc}") from exc
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.cs_abi_version.restype = i32
     L.cs_last_error.restype = C.c_char_p
