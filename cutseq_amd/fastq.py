@@ -14,6 +14,7 @@ import queue
 import threading
 import zlib
 from dataclasses import dataclass
+from pathlib import Path
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -96,6 +97,20 @@ class _Stream:
         self.buf = b""
         self.eof = False
         self.records_out = 0
+        # decompression runs ahead in its own thread (zlib releases the GIL)
+        self._q: "queue.Queue" = queue.Queue(maxsize=4)
+        self._t = threading.Thread(target=self._pump, daemon=True)
+        self._t.start()
+
+    def _pump(self):
+        try:
+            while True:
+                block = self.fh.read(_READ_BLOCK)
+                self._q.put(block)
+                if not block:
+                    break
+        except BaseException as exc:  # surfaced by the consumer
+            self._q.put(exc)
 
     def fill(self, want_records: int):
         """Read until at least ``want_records`` complete records are buffered (or EOF).
@@ -107,7 +122,9 @@ class _Stream:
                                   C.byref(consumed), C.byref(longest))
             if n >= want_records or self.eof:
                 return int(n), int(consumed.value), int(longest.value)
-            block = self.fh.read(_READ_BLOCK)
+            block = self._q.get()
+            if isinstance(block, BaseException):
+                raise block
             if not block:
                 self.eof = True
             else:
@@ -186,8 +203,11 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     if chunk.paired:
         suf2 = [s.encode() for s in plan.r2.name_suffixes] + [None, None]
         fp.suffix2[0], fp.suffix2[1] = suf2[0], suf2[1]
-    cap_bytes = [len(chunk.raw1) + 264 * chunk.n + 16,
-                 (len(chunk.raw2) + 264 * chunk.n + 16) if chunk.paired else 16]
+    # worst case per record: header (<= raw bytes in total) + '_' + two captures (<= 510) + sequence
+    # + quality + "@\n\n+\n\n"
+    per_rec = 2 * chunk.stride + 520
+    cap_bytes = [len(chunk.raw1) + per_rec * chunk.n + 16,
+                 (len(chunk.raw2) + per_rec * chunk.n + 16) if chunk.paired else 16]
     bufs = [[np.empty(cap_bytes[m], dtype=np.uint8) for m in range(2)] for _ in range(3)]
     out_ptrs = ((C.c_void_p * 2) * 3)()
     for r in range(3):
@@ -213,15 +233,35 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     return data, [int(c) for c in counts]
 
 
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        from .synth import usable_cpus
+        _POOL = ThreadPoolExecutor(max_workers=max(2, usable_cpus(32)))
+    return _POOL
+
+
+def _gzip_member(data: bytes, level: int) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)
+    return c.compress(data) + c.flush()
+
+
 class OutputFile:
-    """One output file with its own writer thread; ``.gz`` names get gzip level 1 (cutadapt's
-    default compression level), anything else is written plain."""
+    """One output file.  ``.gz`` names are written as a sequence of gzip members (level 1 =
+    cutadapt's default), one member per block, compressed in a shared thread pool and written
+    in order by the file's own writer thread; anything else is written plain.  The decompressed
+    byte stream is what parity is defined on."""
 
     def __init__(self, path: str, level: int = 1):
         self.path = path
+        self.level = level
+        self.gz = path.endswith(".gz")
         self.fh = open(path, "wb")
-        self.comp = zlib.compressobj(level, zlib.DEFLATED, 31) if path.endswith(".gz") else None
-        self.q: "queue.Queue[Optional[bytes]]" = queue.Queue(maxsize=8)
+        self.q: "queue.Queue" = queue.Queue(maxsize=16)
         self.err: Optional[BaseException] = None
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
@@ -232,20 +272,25 @@ class OutputFile:
                 item = self.q.get()
                 if item is None:
                     break
-                self.fh.write(self.comp.compress(item) if self.comp else item)
-            if self.comp:
-                self.fh.write(self.comp.flush())
+                self.fh.write(item.result() if self.gz else item)
         except BaseException as exc:  # pragma: no cover
             self.err = exc
         finally:
             self.fh.close()
 
     def write(self, data: bytes):
-        if data:
+        if not data:
+            return
+        if self.gz:
+            self.q.put(_pool().submit(_gzip_member, data, self.level))
+        else:
             self.q.put(data)
 
     def close(self):
         self.q.put(None)
         self.t.join()
+        if self.gz and self.fh.closed and Path(self.path).stat().st_size == 0:
+            with open(self.path, "wb") as fh:  # an empty stream is still a valid gzip file
+                fh.write(_gzip_member(b"", self.level))
         if self.err:
             raise self.err
