@@ -277,3 +277,39 @@ def test_filter_is_result_neutral_on_large_batch():
         with TrimEngine(tp, device=0, slots=1, max_reads=b.n, max_stride=b.stride) as eng:
             out.append(eng.trim(b.seq1, b.qual1, b.len1, b.seq2, b.qual2, b.len2))
     assert (out[0][0] == out[1][0]).all() and (out[0][2] == out[1][2]).all()
+
+
+def test_engine_reuse_and_concurrent_engines():
+    """One engine across many launches (the tile hand-out counter is reset per launch), several
+    engines alive at once (one __constant__ plan slot each), a ninth engine is refused."""
+    from cutseq_amd import capi
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp_a = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    tp_b = util.compile_plan(BUILDIN_ADAPTERS["INLINE"], planmod.CutadaptConfig(), True)
+    ba = synth.generate_pairs(5000, 150, seed=3)
+    bb = synth.generate_pairs(5000, 150, BUILDIN_ADAPTERS["INLINE"], seed=4)
+    (oa1, _, _), (oa2, _, _) = util.oracle_run(tp_a, ba)
+    (ob1, _, _), (ob2, _, _) = util.oracle_run(tp_b, bb)
+    with TrimEngine(tp_a, slots=2, max_reads=5000, max_stride=152) as ea, \
+            TrimEngine(tp_b, slots=2, max_reads=5000, max_stride=152) as eb:
+        for rep in range(6):
+            ra = ea.submit(rep & 1, ba.seq1, ba.qual1, ba.len1, ba.seq2, ba.qual2, ba.len2)
+            rb = eb.submit(rep & 1, bb.seq1, bb.qual1, bb.len1, bb.seq2, bb.qual2, bb.len2)
+            ea.wait(rep & 1)
+            eb.wait(rep & 1)
+            assert (ra[0] == oa1).all() and (ra[2] == oa2).all()
+            assert (rb[0] == ob1).all() and (rb[2] == ob2).all()
+        s1, _ = ea.stats()
+        assert s1.n_reads == 6 * 5000
+    engines = []
+    try:
+        for _ in range(8):
+            engines.append(TrimEngine(tp_a, slots=0))
+        with pytest.raises(capi.CsError):
+            TrimEngine(tp_a, slots=0)
+    finally:
+        for e in engines:
+            e.close()
+    with TrimEngine(tp_a, slots=0):  # slots are released on close
+        pass
