@@ -128,6 +128,16 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
         out.peq[b] = mask;
       }
       out.acgt_only = (acgt && op.m <= 64) ? 1u : 0u;
+      // fixed-point error rate: thr[L] == (L * mul) >> 16 for all L <= m, if such a mul exists
+      out.thr_mul = 0;
+      if (op.m >= 1 && op.thr[op.m] > 0) {
+        const uint32_t guess = (uint32_t)(((uint64_t)op.thr[op.m] << 16) / op.m);
+        for (uint32_t mul = guess; mul <= guess + 4096 && !out.thr_mul; ++mul) {
+          bool ok = true;
+          for (uint32_t L = 0; L <= op.m && ok; ++L) ok = ((L * mul) >> 16) == op.thr[L];
+          if (ok) out.thr_mul = mul;
+        }
+      }
       for (int i = 1; i <= op.m; ++i)
         if (op.thr[i] != op.thr[i - 1]) out.thr_step[(i - 1) >> 6] |= 1ull << ((i - 1) & 63);
       out.filter_mode = csdev::FILTER_NONE;
