@@ -1,0 +1,167 @@
+"""Run statistics and the two reports the reference emits: the stderr TSV line
+(``minimal_report``, cutseq/run.py:489, 810) and ``--json-file`` (``json_report``,
+cutseq/run.py:222-302).
+
+The reference fills both from cutadapt's ``Statistics`` object.  cutadapt is not available to
+this build, so the field layout below follows cutadapt's ``minimal_report`` / ``Statistics.as_json``
+as recalled (same caveat as the trimming semantics: unpinned).  One reference quirk is kept on
+purpose: cutseq patches ``Statistics._collect_modifier`` to swallow the assertion that fires on a
+second ``AdapterCutter`` (run.py:59-73), so ``w/adapters`` and ``adapters_read*`` only ever
+describe the FIRST AdapterCutter of each mate's chain.
+"""
+from __future__ import annotations
+
+import json
+from typing import List, Optional
+
+import numpy as np
+
+from . import __version__, abi
+from .plan import AdapterOp, MateChain, TrimPlan
+
+# cutadapt's filter identifiers, in report order
+FILTER_KEYS = ("too_short", "too_long", "too_many_n", "too_many_expected_errors", "casava_filtered",
+               "discard_trimmed", "discard_untrimmed")
+
+# Adapter.descriptive_identifier() of the classes the reference instantiates
+ADAPTER_TYPES = {
+    "BackAdapter": ("three_prime_end", "regular_three_prime"),
+    "RightmostFrontAdapter": ("five_prime_end", "rightmost_five_prime"),
+    "PrefixAdapter": ("five_prime_end", "anchored_five_prime"),
+    "SuffixAdapter": ("three_prime_end", "anchored_three_prime"),
+    "NonInternalBackAdapter": ("three_prime_end", "noninternal_three_prime"),
+    "NonInternalFrontAdapter": ("five_prime_end", "noninternal_five_prime"),
+}
+
+
+def new_totals() -> dict:
+    return {"in_pairs": 0, "routes": [0, 0, 0], "in_bp": [0, 0], "out_bp": [0, 0], "written_bp": [0, 0]}
+
+
+def account_chunk(totals: dict, tp: TrimPlan, len1: np.ndarray, res1: np.ndarray,
+                  len2: Optional[np.ndarray] = None, res2: Optional[np.ndarray] = None) -> None:
+    """Fold one chunk's results into the run totals.  ``written_bp`` counts what reaches the final
+    sink only (cutadapt's ``written_bp``): pairs routed to the short / untrimmed files are excluded."""
+    flags = res1["flags"].astype(np.uint8)
+    if res2 is not None:
+        flags = flags | res2["flags"].astype(np.uint8)
+    dropped = (flags & abi.CS_F_TOO_SHORT) != 0
+    if tp.untrimmed_filter:
+        dropped |= (flags & abi.CS_F_UNTRIMMED) != 0
+    keep = ~dropped
+    totals["in_pairs"] += int(len(res1))
+    for m, (lens, res) in enumerate(((len1, res1), (len2, res2))):
+        if res is None:
+            continue
+        span = res["stop"].astype(np.int64) - res["start"].astype(np.int64)
+        totals["in_bp"][m] += int(lens.sum(dtype=np.int64))
+        totals["out_bp"][m] += int(span.sum())
+        totals["written_bp"][m] += int(span[keep].sum())
+
+
+def first_adapter(chain: Optional[MateChain]):
+    """(stat slot, op) of the first AdapterCutter in a mate's chain, or (None, None)."""
+    if chain is None:
+        return None, None
+    for slot, op in enumerate(chain.ops):
+        if isinstance(op, AdapterOp):
+            return slot, op
+    return None, None
+
+
+def _mate_sum(totals: dict, mate: int, field: str) -> int:
+    return sum(int(getattr(pair[mate], field)) for pair in totals["stats"])
+
+
+def _matched(totals: dict, mate: int, slot: Optional[int]) -> int:
+    if slot is None:
+        return 0
+    return sum(int(pair[mate].op_matched[slot]) for pair in totals["stats"])
+
+
+def minimal_report(tp: TrimPlan, totals: dict) -> str:
+    """Header line + value line, tab separated (cutadapt ``minimal_report`` field order)."""
+    fields = ["status", "in_reads", "in_bp", "too_short", "too_long", "too_many_n", "out_reads",
+              "w/adapters", "qualtrim_bp", "out_bp"]
+    s1, _ = first_adapter(tp.r1)
+    vals = ["OK", totals["in_pairs"], sum(totals["in_bp"]), totals["routes"][1], 0, 0, totals["routes"][0],
+            _matched(totals, 0, s1), _mate_sum(totals, 0, "qualtrim_bp"), totals["written_bp"][0]]
+    if tp.paired:
+        s2, _ = first_adapter(tp.r2)
+        fields += ["w/adapters2", "qualtrim2_bp", "out2_bp"]
+        vals += [_matched(totals, 1, s2), _mate_sum(totals, 1, "qualtrim_bp"), totals["written_bp"][1]]
+    return "\t".join(fields) + "\n" + "\t".join(str(v) for v in vals)
+
+
+def _adapter_json(op: AdapterOp, name: str, matches: int) -> dict:
+    end, type_name = ADAPTER_TYPES[op.kind_name]
+    side = {
+        "type": type_name,
+        "sequence": op.sequence,
+        "error_rate": op.max_error_rate,
+        "indels": True,
+        "error_lengths": None,  # per-error-count histograms are not collected on the device
+        "matches": matches,
+        "adjacent_bases": None,
+        "dominant_adjacent_base": None,
+        "trimmed_lengths": [],  # the reference empties these lists itself (run.py:286-300)
+    }
+    d = {"name": name, "total_matches": matches, "on_reverse_complement": None, "linked": False,
+         "five_prime_end": None, "three_prime_end": None}
+    d[end] = side
+    return d
+
+
+def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, output2, short1, short2,
+                untrimmed1, untrimmed2) -> dict:
+    """Same header block as the reference's ``json_report`` (run.py:262-283) followed by the
+    ``Statistics.as_json()`` sections; engine-specific counters live under ``"engine"``."""
+    paired = tp.paired
+    s1, a1 = first_adapter(tp.r1)
+    s2, a2 = first_adapter(tp.r2) if paired else (None, None)
+    filtered = {k: None for k in FILTER_KEYS}
+    filtered["too_short"] = totals["routes"][1]
+    q1, q2 = _mate_sum(totals, 0, "qualtrim_bp"), (_mate_sum(totals, 1, "qualtrim_bp") if paired else None)
+    d = {
+        "tag": "Cutadapt report",
+        "cutadapt_version": None,  # no cutadapt in this engine
+        "engine": {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
+                   "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
+                   "per_device": [[s.as_dict() for s in pair] for pair in totals["stats"]]},
+        "input": {"path1": input1, "path2": input2, "paired": True if input2 else False},
+        "output": {"output1": output1, "output2": output2, "short1": short1, "short2": short2,
+                   "untrimmed1": untrimmed1, "untrimmed2": untrimmed2},
+        "barcode": barcode.to_dict(),
+        "read_counts": {
+            "input": totals["in_pairs"],
+            "filtered": filtered,
+            "output": totals["routes"][0],
+            "reverse_complemented": None,
+            "read1_with_adapter": _matched(totals, 0, s1) if a1 is not None else None,
+            "read2_with_adapter": (_matched(totals, 1, s2) if a2 is not None else None) if paired else None,
+        },
+        "basepair_counts": {
+            "input": sum(totals["in_bp"]),
+            "input_read1": totals["in_bp"][0],
+            "input_read2": totals["in_bp"][1] if paired else None,
+            "quality_trimmed": q1 + (q2 or 0),
+            "quality_trimmed_read1": q1,
+            "quality_trimmed_read2": q2,
+            "poly_a_trimmed": None,  # cutadapt's PolyATrimmer is not in the reference's chain
+            "poly_a_trimmed_read1": None,
+            "poly_a_trimmed_read2": None,
+            "output": sum(totals["written_bp"]),
+            "output_read1": totals["written_bp"][0],
+            "output_read2": totals["written_bp"][1] if paired else None,
+        },
+        "adapters_read1": [_adapter_json(a1, "1", _matched(totals, 0, s1))] if a1 is not None else [],
+        "adapters_read2": ([_adapter_json(a2, "2", _matched(totals, 1, s2))] if a2 is not None else []) if paired else None,
+        "poly_a_trimmed_read1": None,
+        "poly_a_trimmed_read2": None,
+    }
+    return d
+
+
+def write_json(path: str, report: dict) -> None:
+    with open(path, "w") as fh:
+        fh.write(json.dumps(report, indent=2))

@@ -20,7 +20,7 @@ import time
 from collections import deque
 from typing import List, Optional
 
-from . import __version__, abi
+from . import __version__, abi, report
 from .common import BUILDIN_ADAPTERS, BarcodeConfig, print_builtin_adapters, remove_fq_suffix
 from .plan import CutadaptConfig, TrimPlan, compile_paired, compile_single
 
@@ -210,7 +210,7 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     stride_cap = {}
     slots_per_engine = 2
     inflight = deque()  # (engine, slot, chunk, result arrays)
-    totals = {"in_pairs": 0, "routes": [0, 0, 0], "in_bp": [0, 0], "out_bp": [0, 0]}
+    totals = report.new_totals()
     t0 = time.perf_counter()
 
     def engine_for(dev, stride):
@@ -234,12 +234,7 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
                 fh = outs[route][m]
                 if fh is not None:
                     fh.write(data[route][m])
-        totals["in_pairs"] += chunk.n
-        totals["in_bp"][0] += int(chunk.len1.sum(dtype="int64"))
-        totals["out_bp"][0] += int((r1["stop"].astype("int64") - r1["start"]).sum())
-        if paired:
-            totals["in_bp"][1] += int(chunk.len2.sum(dtype="int64"))
-            totals["out_bp"][1] += int((r2["stop"].astype("int64") - r2["start"]).sum())
+        report.account_chunk(totals, tp, chunk.len1, r1, chunk.len2 if paired else None, r2 if paired else None)
 
     try:
         k = 0
@@ -273,21 +268,6 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     return totals
 
 
-def minimal_report(tp: TrimPlan, totals: dict) -> str:
-    """One header + one value line on stderr, in the spirit of cutadapt's ``minimal_report``
-    (run.py:489, 810).  Field semantics follow this engine's counters (not parity-checked)."""
-    st = totals["stats"]
-    m1 = [s[0] for s in st]
-    m2 = [s[1] for s in st]
-    fields = ["status", "in_reads", "in_bp", "too_short", "out_reads", "w/adapters", "qualtrim_bp", "out_bp"]
-    vals = ["OK", totals["in_pairs"], sum(totals["in_bp"]), totals["routes"][1], totals["routes"][0],
-            sum(int(s.op_matched[0]) for s in m1), sum(int(s.qualtrim_bp) for s in m1), totals["out_bp"][0]]
-    if tp.paired:
-        fields += ["w/adapters2", "qualtrim2_bp", "out2_bp"]
-        vals += [sum(int(s.op_matched[0]) for s in m2), sum(int(s.qualtrim_bp) for s in m2), totals["out_bp"][1]]
-    return "\t".join(fields) + "\n" + "\t".join(str(v) for v in vals)
-
-
 def run_cutseq(args):
     barcode = BarcodeConfig(args.adapter_scheme)
     settings = settings_from_args(args)
@@ -297,27 +277,14 @@ def run_cutseq(args):
         return None
     totals = run_pipeline(args, tp)
     if args.json_file:
-        import json
-
-        report = {
-            "tag": "cutseq_amd report",
-            "engine_version": __version__,
-            "input": {"path1": args.input_file[0], "path2": args.input_file[1] if tp.paired else None,
-                      "paired": tp.paired},
-            "output": {"output1": args.output_file[0], "output2": args.output_file[1] if tp.paired else None,
-                       "short1": args.short_file[0], "short2": args.short_file[1] if tp.paired else None,
-                       "untrimmed1": args.untrimmed_file[0],
-                       "untrimmed2": args.untrimmed_file[1] if tp.paired else None},
-            "barcode": barcode.to_dict(),
-            "read_counts": {"input": totals["in_pairs"], "output": totals["routes"][0],
-                            "too_short": totals["routes"][1], "untrimmed": totals["routes"][2]},
-            "basepair_counts": {"input": sum(totals["in_bp"]), "output": sum(totals["out_bp"])},
-            "mates": [[s.as_dict() for s in pair] for pair in totals["stats"]],
-            "seconds": totals["seconds"],
-        }
-        with open(args.json_file, "w") as fh:
-            fh.write(json.dumps(report, indent=2))
-    print(minimal_report(tp, totals), file=sys.stderr)
+        paired = tp.paired
+        rep = report.json_report(
+            tp, totals, barcode, args.input_file[0], args.input_file[1] if paired else None,
+            args.output_file[0], args.output_file[1] if paired else None,
+            args.short_file[0], args.short_file[1] if paired else None,
+            args.untrimmed_file[0], args.untrimmed_file[1] if paired else None)
+        report.write_json(args.json_file, rep)
+    print(report.minimal_report(tp, totals), file=sys.stderr)
     return totals
 
 

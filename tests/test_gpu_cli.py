@@ -47,9 +47,11 @@ def test_cli_paired_takarav3(tmp_path, capsys):
         assert gunzip(f"{prefix}_{kind}_R2.fastq.gz") == want[kind][1]
     rep = json.loads((tmp_path / "r.json").read_text())
     assert rep["read_counts"]["input"] == 1000
-    assert rep["read_counts"]["output"] + rep["read_counts"]["too_short"] == 1000
+    assert rep["read_counts"]["output"] + rep["read_counts"]["filtered"]["too_short"] == 1000
+    assert rep["basepair_counts"]["output_read1"] == sum(len(l) for l in want["trimmed"][0].split(b"\n")[1::4])
+    assert rep["tag"] == "Cutadapt report" and rep["engine"]["name"] == "cutseq_amd"
     err = capsys.readouterr().err
-    assert "status\tin_reads" in err and "\nOK\t1000\t" in err
+    assert "status\tin_reads\tin_bp\ttoo_short\ttoo_long\ttoo_many_n\tout_reads" in err and "\nOK\t1000\t" in err
 
 
 def test_cli_paired_auto_rc_swaps_outputs(tmp_path):

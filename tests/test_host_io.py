@@ -180,3 +180,61 @@ def test_cli_dry_run_lists_the_chain(capsys):
     cli.main(["-A", "TAKARAV3", "-n", "r_R1.fq.gz", "r_R2.fq.gz"])
     out = capsys.readouterr().out
     assert "p5: ACACGACGCTCTTCCGATCT (AGATCGGAAGAGCGTCGTGT)" in out and "strand: -" in out
+
+
+# ---------------------------------------------------------------- reports (run.py:222-302, 489, 810)
+
+
+def test_reports_from_oracle_results():
+    """TSV + JSON reports assembled from per-read results; counters cross-checked against a direct
+    recount over the formatted records (results come from the oracle, no GPU involved)."""
+    from cutseq_amd import report
+
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    rec1 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R1.fq.gz")
+    rec2 = util.read_fastq_gz(util.GOLDEN / "fixture1k_R2.fq.gz")
+    batch = util.batch_from_records(rec1, rec2)
+    (r1, cap2, s1), (r2, _, s2) = util.oracle_run(tp, batch)
+    totals = report.new_totals()
+    half = 500  # two chunks, like the streaming loop
+    for lo in (0, half):
+        sl = slice(lo, lo + half)
+        report.account_chunk(totals, tp, batch.len1[sl], r1[sl], batch.len2[sl], r2[sl])
+    want = util.format_batch(tp, batch, [r[0] for r in rec1], [r[0] for r in rec2], r1, cap2, r2)
+    for route in range(3):
+        totals["routes"][route] = sum(1 for x in want if x[0] == route)
+    totals["stats"] = [(s1, s2)]
+    totals["devices"], totals["seconds"] = [0], 0.0
+
+    def written_bp(mate):
+        return sum(len(x[mate].split(b"\n")[1]) for x in want if x[0] == 0)
+
+    head, vals = report.minimal_report(tp, totals).split("\n")
+    row = dict(zip(head.split("\t"), vals.split("\t")))
+    assert head.split("\t") == ["status", "in_reads", "in_bp", "too_short", "too_long", "too_many_n", "out_reads",
+                                "w/adapters", "qualtrim_bp", "out_bp", "w/adapters2", "qualtrim2_bp", "out2_bp"]
+    assert row["status"] == "OK" and int(row["in_reads"]) == 1000
+    assert int(row["in_bp"]) == int(batch.len1.sum()) + int(batch.len2.sum())
+    assert int(row["too_short"]) + int(row["out_reads"]) == 1000
+    assert int(row["out_bp"]) == written_bp(1) and int(row["out2_bp"]) == written_bp(2)
+    # first AdapterCutter of each mate only (run.py:59-73): R1's chain starts with the 5' adapter
+    slot1, op1 = report.first_adapter(tp.r1)
+    assert op1.kind_name == "RightmostFrontAdapter"
+    assert int(row["w/adapters"]) == int(s1.op_matched[slot1])
+    assert int(row["w/adapters"]) == int(np.count_nonzero(r1["flags"] & abi.CS_F_ADAPTER5))
+
+    bc = BarcodeConfig(BUILDIN_ADAPTERS["TAKARAV3"])
+    rep = report.json_report(tp, totals, bc, "a_R1.fq.gz", "a_R2.fq.gz", "o1", "o2", "s1", "s2", None, None)
+    json.dumps(rep)  # serialisable
+    assert rep["tag"] == "Cutadapt report" and rep["input"]["paired"] is True
+    assert rep["barcode"] == bc.to_dict()
+    rc, bp = rep["read_counts"], rep["basepair_counts"]
+    assert rc["input"] == 1000 and rc["output"] + rc["filtered"]["too_short"] == 1000
+    assert set(rc["filtered"]) == set(report.FILTER_KEYS)
+    assert bp["output"] == written_bp(1) + written_bp(2) and bp["input"] == int(row["in_bp"])
+    assert bp["quality_trimmed"] == int(s1.qualtrim_bp) + int(s2.qualtrim_bp)
+    (a,) = rep["adapters_read1"]
+    assert a["five_prime_end"]["sequence"] == op1.sequence and a["three_prime_end"] is None
+    assert a["five_prime_end"]["trimmed_lengths"] == []
