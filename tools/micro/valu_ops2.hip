@@ -1,0 +1,95 @@
+// Microbenchmark: issue rate per VALU opcode on gfx950 (8 independent chains per lane, wave64,
+// 16 waves/CU).  hipcc --offload-arch=gfx950 -O3 -o valu_ops valu_ops.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define OPS(X)                                                                                   \
+  X(0, "v_or_b32 %0, %0, %1")                                                                    \
+  X(1, "v_not_b32 %0, %0")                                                                       \
+  X(2, "v_cndmask_b32 %0, %0, %1, vcc")                                                          \
+  X(3, "v_min_u32 %0, %0, %1")                                                                   \
+  X(4, "v_and_b32 %0, 0x12345678, %0")                                                           \
+  X(5, "v_and_b32 %0, s12, %0")                                                                  \
+  X(6, "v_add_u32 %0, 5, %0")                                                                    \
+  X(7, "v_subrev_u32 %0, %1, %0")                                                                \
+  X(8, "v_lshlrev_b32 %0, 3, %0")                                                                \
+  X(9, "v_lshrrev_b32 %0, 3, %0")                                                                \
+  X(10, "v_pk_add_u16 %0, %0, %1")                                                               \
+  X(11, "v_pk_min_i16 %0, %0, %1")                                                               \
+  X(12, "v_bitop3_b32 %0, %0, %1, s12 bitop3:0xc4")                                              \
+  X(13, "v_add_u16 %0, %0, %1")                                                                  \
+  X(14, "v_min_i16 %0, %0, %1")                                                                  \
+  X(15, "v_sub_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0") \
+  X(16, "v_bfrev_b32 %0, %0")                                                                    \
+  X(17, "v_ffbl_b32 %0, %0")                                                                     \
+  X(18, "v_cvt_f32_u32 %0, %0")                                                                  \
+  X(19, "v_add_f32 %0, %0, %1")                                                                  \
+  X(20, "v_fma_f32 %0, %0, %1, %2")                                                              \
+  X(21, "v_max_f32 %0, %0, %1")                                                                  \
+  X(22, "v_min_f32 %0, %0, %1")                                                                  \
+  X(24, "v_med3_i32 %0, %0, %1, %2")                                                             \
+  X(25, "v_sad_u32 %0, %0, %1, %2")                                                              \
+  X(26, "v_addc_co_u32 %0, vcc, %0, %1, vcc")                                                    \
+  X(27, "v_mov_b32 %0, %1")                                                                      \
+  X(28, "v_xnor_b32 %0, %0, %1")                                                                 \
+  X(29, "v_bitop3_b16 %0, %0, %1, %2 bitop3:0xc4")                                               \
+  X(30, "v_dot4_u32_u8 %0, %0, %1, %2")                                                          \
+  X(31, "v_cmp_eq_u32 vcc, %0, %1")                                                              \
+  X(33, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")                   \
+  X(34, "v_max3_i32 %0, %0, %1, %2")                                                             \
+  X(35, "v_lshl_add_u32 %0, %0, 0, %1")
+
+template <int KIND>
+__global__ void k(uint32_t *out, int iters, uint32_t seed) {
+  uint32_t a[8], b[8], c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = threadIdx.x * (2 * i + 3) + seed;
+    b[i] = a[i] * 77u + 1u;
+    c[i] = a[i] ^ 0x55aa55aau;
+    asm volatile("" : "+v"(b[i]), "+v"(c[i]));
+  }
+  asm volatile("s_mov_b64 s[10:11], 0x5555\n s_mov_b64 vcc, 0x3333\n s_mov_b32 s12, 0x77" ::: "s10", "s11", "s12", "vcc");
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#define X(ID, TEXT) \
+  if (KIND == ID) asm volatile(TEXT : "+v"(a[i]) : "v"(b[i]), "v"(c[i]) : "vcc", "s10", "s11");
+        OPS(X)
+#undef X
+      }
+    }
+  }
+  uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r ^= a[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int KIND>
+void run(const char *name, uint32_t *d, hipEvent_t e0, hipEvent_t e1) {
+  const int iters = 1000, wpc = 16;
+  int blocks = 256 * wpc;
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, d, iters, 1u);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  double n = (double)iters * 64 * blocks;
+  printf("%.3f instr/clk/SIMD  %s\n", n / (ms * 1e-3) / (1024 * 2.4e9), name);
+}
+int main() {
+  uint32_t *d;
+  (void)hipMalloc(&d, 256 * 32 * 64 * 4);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+#define X(ID, TEXT) run<ID>(TEXT, d, e0, e1);
+  OPS(X)
+#undef X
+  return 0;
+}
