@@ -115,9 +115,10 @@ def test_adapter_with_non_acgt_base():
     run_both(tp, batch, threads=4)
 
 
+@pytest.mark.parametrize("rule", [0, 1])
 @pytest.mark.parametrize("base,where", [("A", "BACK_NI"), ("T", "FRONT_NI"), ("A", "BACK"), ("G", "SUFFIX")])
 @pytest.mark.parametrize("m,rate,mo", [(100, 0.15, 3), (20, 0.2, 3), (100, 0.4, 3), (8, 0.5, 5)])
-def test_homopolymer_adapters(base, where, m, rate, mo):
+def test_homopolymer_adapters(base, where, m, rate, mo, rule):
     """poly-A/T ops (cutseq/run.py:388-413): mismatch-count pre-filter + windowed DP."""
     rng = random.Random(m * 7 + len(where))
     reads = []
@@ -130,8 +131,30 @@ def test_homopolymer_adapters(base, where, m, rate, mo):
             s = util.mutate(rng, s, 2)
         reads.append((s, "I" * len(s)))
     tp = one_adapter_plan(base * m, rate, mo, WHERE[where], abi.CS_REMOVE_AFTER if "BACK" in where or where == "SUFFIX"
-                          else abi.CS_REMOVE_BEFORE)
+                          else abi.CS_REMOVE_BEFORE, rule=rule)
     run_both(tp, util.batch_from_reads(reads), threads=4)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("where,base", [("BACK_NI", "A"), ("FRONT_NI", "T")])
+def test_poly_runs_with_scattered_errors(where, base, rule):
+    """Long noisy homopolymer runs: many candidate rows, spans beyond m/2 (the leftmost rule's overlap
+    window), runs cut by foreign bases right at the threshold steps -- the cases the closed form's
+    "visit only where it can matter" short cut has to get right."""
+    rng = random.Random(99 + rule + len(where))
+    reads = []
+    for _ in range(3000):
+        parts = []
+        for _ in range(rng.randint(1, 6)):
+            parts.append(base * rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 30, 51, 52]))
+            parts.append(util.random_dna(rng, rng.choice([0, 1, 1, 1, 2, 3]), "ACGTN"))
+        run = "".join(parts)[: rng.choice([20, 60, 100, 101, 140])]
+        body = util.random_dna(rng, rng.choice([0, 0, 1, 5, 40]))
+        s = (body + run) if where == "BACK_NI" else (run[::-1] + body)
+        reads.append((s, "I" * len(s)))
+    remove = abi.CS_REMOVE_AFTER if where == "BACK_NI" else abi.CS_REMOVE_BEFORE
+    for m, rate in ((100, 0.15), (100, 0.3), (24, 0.25)):
+        run_both(one_adapter_plan(base * m, rate, 3, WHERE[where], remove, rule=rule), util.batch_from_reads(reads), threads=8)
 
 
 @pytest.mark.parametrize("rule", [0, 1])
