@@ -190,16 +190,12 @@ int geometry_for(const cs_engine *eng, uint32_t stride, Geometry &g) {
     const long v = atol(env);
     if (v >= 1024 && v <= 32768 && (uint32_t)v / 4 > g.col_dwords) g.col_dwords = (uint32_t)v / 4;
   }
-  uint32_t rows = kTileRows;
-  if (const char *env = getenv("CUTSEQ_TILE_ROWS")) {  // tuning knob: reads per block (64..256)
-    const long v = atol(env);
-    if (v == 64 || v == 128 || v == 192 || v == 256) rows = (uint32_t)v;
-  }
+  uint32_t rows = kTileRows;  // one wave per block: the kernel keeps per-block state (private mask table) on that basis
   for (;;) {
     const uint32_t waves = rows / 64;
     const uint32_t words = rows * g.lds_stride_dw + waves * (g.col_dwords + 64 * csdev::kWaveItemDwords) +
                            eng->n_table_ops * (csdev::kEqTableBytes / 4) + csdev::kStatWords +
-                           64 /* next-tile slot + look-ahead pad */;
+                           96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
     g.lds_bytes = words * 4;
     if (g.lds_bytes <= kLdsBudget || rows == 64) break;
     rows -= 64;
