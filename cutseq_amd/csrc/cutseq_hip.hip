@@ -32,6 +32,7 @@ int fail(int code, const char *fmt, ...) {
                                       __FILE__, __LINE__);                                         \
   } while (0)
 
+constexpr size_t kTileCounterBytes = 2 * csdev::kTileCounters * csdev::kTileCounterStride * sizeof(uint32_t);
 constexpr uint32_t kTileRows = 64;  // one wave per block: no block-level synchronisation at all
 constexpr uint32_t kLdsBudget = 160 * 1024;
 
@@ -251,9 +252,25 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
   }
   if (gx < 1) gx = 1;
   if (gx > n_tiles) gx = n_tiles;
+  // tile hand-out (see the kernel): big units, about a quarter of a block's share (at most 8 tiles), for
+  // the first 3/4 of the batch, single tiles for the rest.
+  a.static_units = gx / 2 > 0 ? gx / 2 : 1;  // the half of the grid that is resident from the start
+  const uint32_t share = n_tiles / a.static_units;
+  a.big_shift = share >= 32 ? 3 : share >= 16 ? 2 : 1;
+  a.small_shift = 0;
+  uint32_t big_pct = 75;
+  if (const char *env = getenv("CUTSEQ_UNITS")) {  // tuning knob: "big_shift,small_shift,big_pct"
+    unsigned bs, ss, pc;
+    if (sscanf(env, "%u,%u,%u", &bs, &ss, &pc) == 3 && bs <= 6 && ss <= bs && pc <= 100) {
+      a.big_shift = bs;
+      a.small_shift = ss;
+      big_pct = pc;
+    }
+  }
+  a.big_tiles = (uint32_t)((uint64_t)n_tiles * big_pct / 100) & ~((1u << a.big_shift) - 1u);
   dim3 grid(gx, mates, 1);
   dim3 block(g.tile_rows, 1, 1);
-  HIP_TRY(hipMemsetAsync(eng->d_tile_counter, 0, 2 * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(eng->d_tile_counter, 0, kTileCounterBytes, stream));
   if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
   void *kargs[] = {&a};
   HIP_TRY(hipLaunchKernel(kernel_for(eng), grid, block, kargs, g.lds_bytes, stream));
@@ -412,7 +429,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
                             (size_t)eng->plan_slot * sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
   ENG_TRY(hipMalloc(&eng->d_stats, 2 * sizeof(cs_stats)));
   ENG_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
-  ENG_TRY(hipMalloc(&eng->d_tile_counter, 2 * sizeof(uint32_t)));
+  ENG_TRY(hipMalloc(&eng->d_tile_counter, kTileCounterBytes));
   eng->slots.resize(n_slots);
   const size_t bytes = (size_t)max_reads * max_stride;
   for (Slot &s : eng->slots) {
