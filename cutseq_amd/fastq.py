@@ -22,7 +22,7 @@ import numpy as np
 from . import abi
 from .synth import host_lib as _host_lib
 
-CHUNK_READS = 1 << 18
+CHUNK_READS = 1 << 16
 _READ_BLOCK = 8 << 20
 
 
@@ -48,6 +48,7 @@ def _lib():
         i64, vp = C.c_int64, C.c_void_p
         L.csh_fastq_count.restype = i64
         L.csh_fastq_count.argtypes = [vp, i64, i64, C.c_int, C.POINTER(i64), C.POINTER(C.c_int32)]
+        C.memmove.argtypes = None  # accepts addresses and bytes objects alike
         L.csh_fastq_parse.restype = i64
         L.csh_fastq_parse.argtypes = [vp, i64, i64, C.c_uint32, vp, vp, vp, vp, vp]
         L.csh_format_chunk.restype = i64
@@ -64,6 +65,39 @@ def open_input(path: str):
     if magic == b"\x1f\x8b":
         return gzip.GzipFile(fileobj=fh, mode="rb")
     return fh
+
+
+class _Arena:
+    """Recycles the big per-chunk buffers.  Fresh memory costs a page fault per 4 KB on first touch --
+    more than the parsing and formatting themselves -- so buffers go back here when a chunk is done
+    (:meth:`Chunk.release`) and are handed out again, already mapped."""
+
+    def __init__(self, keep_per_size: int = 48):
+        self._lock = threading.Lock()
+        self._free: dict = {}
+        self._keep = keep_per_size
+
+    @staticmethod
+    def _bucket(nbytes: int) -> int:
+        step = 1 << 16 if nbytes <= (1 << 20) else (1 << 20 if nbytes <= (16 << 20) else 4 << 20)
+        return max(step, (int(nbytes) + step - 1) // step * step)
+
+    def take(self, nbytes: int) -> np.ndarray:
+        size = self._bucket(nbytes)
+        with self._lock:
+            stack = self._free.get(size)
+            if stack:
+                return stack.pop()
+        return np.empty(size, dtype=np.uint8)
+
+    def give(self, arr: np.ndarray) -> None:
+        with self._lock:
+            stack = self._free.setdefault(arr.size, [])
+            if len(stack) < self._keep:
+                stack.append(arr)
+
+
+ARENA = _Arena()
 
 
 @dataclass
@@ -83,114 +117,247 @@ class Chunk:
     qual2: Optional[np.ndarray] = None
     len2: Optional[np.ndarray] = None
 
+    _owned: tuple = ()  # arena buffers behind the arrays above
+
     @property
     def paired(self) -> bool:
         return self.raw2 is not None
 
+    def release(self) -> None:
+        """Hand the chunk's buffers back for reuse; the chunk must not be touched afterwards."""
+        for arr in self._owned:
+            ARENA.give(arr)
+        self._owned = ()
 
-class _Stream:
-    """Incremental reader: keeps the unparsed tail of one input file."""
 
-    def __init__(self, path: str):
-        self.path = path
+class _Failure:
+    """An exception travelling through a queue to the thread that consumes it."""
+
+    def __init__(self, exc: BaseException):
+        self.exc = exc
+
+
+@dataclass
+class _Half:
+    """One mate's share of a chunk, parsed."""
+
+    n: int
+    stride: int
+    raw: bytes
+    name_off: np.ndarray
+    name_len: np.ndarray
+    seq: np.ndarray
+    qual: np.ndarray
+    lens: np.ndarray
+    owned: tuple = ()
+
+
+class _StrideHint:
+    """Row stride shared by the two parser threads: it only grows, so after the first chunk both mates
+    are almost always parsed with the same stride straight away."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._value = 4
+
+    def raise_to(self, longest: int) -> int:
+        want = max(4, (longest + 3) // 4 * 4)
+        with self._lock:
+            if want > self._value:
+                self._value = want
+            return self._value
+
+
+def _raw_pointer(raw):
+    """Address of a bytes / memoryview / ndarray buffer for the native calls."""
+    return raw if isinstance(raw, bytes) else np.frombuffer(raw, dtype=np.uint8).ctypes.data
+
+
+def _parse(path: str, raw, n_records: int, stride: int, first_record: int, raw_owner=()) -> _Half:
+    L = _lib()
+    bufs = [ARENA.take(n_records * stride), ARENA.take(n_records * stride), ARENA.take(n_records * 2),
+            ARENA.take(n_records * 8), ARENA.take(n_records * 4)]
+    seq = bufs[0][: n_records * stride].reshape(n_records, stride)
+    qual = bufs[1][: n_records * stride].reshape(n_records, stride)
+    lens = bufs[2][: n_records * 2].view(np.uint16)
+    noff = bufs[3][: n_records * 8].view(np.int64)
+    nlen = bufs[4][: n_records * 4].view(np.int32)
+    rc = L.csh_fastq_parse(_raw_pointer(raw), len(raw), n_records, stride, seq.ctypes.data, qual.ctypes.data,
+                           lens.ctypes.data, noff.ctypes.data, nlen.ctypes.data)
+    if rc < 0:
+        raise FastqFormatError(
+            f"{path}: malformed FASTQ record {first_record - rc} "
+            "(expected '@' header, sequence, '+' line and a quality line of equal length)")
+    return _Half(n_records, stride, raw, noff, nlen, seq, qual, lens, tuple(bufs) + tuple(raw_owner))
+
+
+class _Reader:
+    """One input file -> parsed halves of ``chunk_reads`` records, through two threads: one inflates
+    (zlib releases the GIL), one cuts at record boundaries and parses (native code, GIL released too).
+    The consumer only pairs the halves up."""
+
+    def __init__(self, path: str, chunk_reads: int, hint: _StrideHint):
+        self.path, self.chunk_reads, self.hint = path, chunk_reads, hint
         self.fh = open_input(path)
-        self.buf = b""
-        self.eof = False
-        self.records_out = 0
-        # decompression runs ahead in its own thread (zlib releases the GIL)
-        self._q: "queue.Queue" = queue.Queue(maxsize=4)
-        self._t = threading.Thread(target=self._pump, daemon=True)
-        self._t.start()
+        self._blocks: "queue.Queue" = queue.Queue(maxsize=4)
+        self.halves: "queue.Queue" = queue.Queue(maxsize=2)
+        self._stop = False
+        self._t1 = threading.Thread(target=self._inflate, daemon=True)
+        self._t2 = threading.Thread(target=self._cut, daemon=True)
+        self._t1.start()
+        self._t2.start()
 
-    def _pump(self):
+    def _put(self, q, item) -> bool:
+        while not self._stop:
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _inflate(self):
         try:
-            while True:
+            while not self._stop:
                 block = self.fh.read(_READ_BLOCK)
-                self._q.put(block)
-                if not block:
+                if not self._put(self._blocks, block) or not block:
                     break
-        except BaseException as exc:  # surfaced by the consumer
-            self._q.put(exc)
+        except BaseException as exc:
+            self._put(self._blocks, _Failure(exc))
 
-    def fill(self, want_records: int):
-        """Read until at least ``want_records`` complete records are buffered (or EOF).
-        -> (records available (<= want), bytes they span, longest sequence)."""
+    def _cut(self):
         L = _lib()
+        # inflated blocks are appended to an arena buffer with ctypes.memmove (GIL released): the
+        # buffer becomes the chunk's raw text, only the short tail behind the last complete record
+        # moves on to the next one
+        buf = ARENA.take(4 * _READ_BLOCK)
+        fill = 0
+        eof = False
+        done = 0       # records handed out so far
+        need = 0       # bytes worth buffering before the next count (from the previous chunk's density)
         consumed, longest = C.c_int64(), C.c_int32()
-        while True:
-            n = L.csh_fastq_count(self.buf, len(self.buf), want_records, 1 if self.eof else 0,
-                                  C.byref(consumed), C.byref(longest))
-            if n >= want_records or self.eof:
-                return int(n), int(consumed.value), int(longest.value)
-            block = self._q.get()
-            if isinstance(block, BaseException):
-                raise block
-            if not block:
-                self.eof = True
-            else:
-                self.buf += block
+        try:
+            while not self._stop:
+                while not eof and fill < max(need, 1):
+                    block = self._blocks.get()
+                    if isinstance(block, _Failure):
+                        raise block.exc
+                    if not block:
+                        eof = True
+                        break
+                    if fill + len(block) > buf.size:
+                        bigger = ARENA.take(max(2 * buf.size, fill + len(block)))
+                        C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
+                        ARENA.give(buf)
+                        buf = bigger
+                    C.memmove(buf.ctypes.data + fill, block, len(block))
+                    fill += len(block)
+                n = L.csh_fastq_count(buf.ctypes.data, fill, self.chunk_reads, 1 if eof else 0, C.byref(consumed),
+                                      C.byref(longest)) if fill else 0
+                if n < self.chunk_reads and not eof:
+                    need = fill + 1  # not there yet: wait for at least one more block
+                    continue
+                if n == 0:
+                    if bytes(memoryview(buf)[:fill]).strip():
+                        raise FastqFormatError(f"{self.path}: truncated FASTQ record at end of file")
+                    ARENA.give(buf)
+                    self._put(self.halves, None)
+                    return
+                used = int(consumed.value)
+                nxt = ARENA.take(max(buf.size, 4 * _READ_BLOCK))
+                C.memmove(nxt.ctypes.data, buf.ctypes.data + used, fill - used)
+                raw = memoryview(buf)[:used]  # compares equal to bytes, slices without copying
+                stride = self.hint.raise_to(int(longest.value))
+                half = _parse(self.path, raw, int(n), stride, done, raw_owner=(buf,))
+                buf, fill = nxt, fill - used
+                done += int(n)
+                need = used + (used >> 6)  # the next chunk will be about as long
+                if not self._put(self.halves, half):
+                    return
+        except BaseException as exc:
+            self._put(self.halves, _Failure(exc))
 
-    def take(self, n_records: int, n_bytes: int, stride: int):
-        L = _lib()
-        raw = self.buf[:n_bytes]
-        seq = np.empty((n_records, stride), dtype=np.uint8)
-        qual = np.empty((n_records, stride), dtype=np.uint8)
-        lens = np.empty(n_records, dtype=np.uint16)
-        noff = np.empty(n_records, dtype=np.int64)
-        nlen = np.empty(n_records, dtype=np.int32)
-        rc = L.csh_fastq_parse(raw, len(raw), n_records, stride, seq.ctypes.data, qual.ctypes.data, lens.ctypes.data,
-                               noff.ctypes.data, nlen.ctypes.data)
-        if rc < 0:
-            raise FastqFormatError(
-                f"{self.path}: malformed FASTQ record {self.records_out - rc} "
-                "(expected '@' header, sequence, '+' line and a quality line of equal length)")
-        self.buf = self.buf[n_bytes:]
-        self.records_out += n_records
-        return raw, noff, nlen, seq, qual, lens
+    def next_half(self) -> Optional[_Half]:
+        item = self.halves.get()
+        if isinstance(item, _Failure):
+            raise item.exc
+        return item
 
     def close(self):
+        self._stop = True
+        for q in (self._blocks, self.halves):  # unblock producers
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
         self.fh.close()
+
+
+def _restride(path: str, half: _Half, stride: int, first_record: int) -> _Half:
+    if half.stride == stride:
+        return half
+    again = _parse(path, half.raw, half.n, stride, first_record, raw_owner=half.owned[5:])
+    for arr in half.owned[:5]:
+        ARENA.give(arr)
+    return again
 
 
 def read_chunks(path1: str, path2: Optional[str] = None, chunk_reads: int = CHUNK_READS):
     """Yield record-aligned :class:`Chunk` objects (equal record counts for both mates)."""
-    s1 = _Stream(path1)
-    s2 = _Stream(path2) if path2 else None
+    hint = _StrideHint()
+    r1 = _Reader(path1, chunk_reads, hint)
+    r2 = _Reader(path2, chunk_reads, hint) if path2 else None
+    done = 0
     try:
         while True:
-            n1, b1, l1 = s1.fill(chunk_reads)
-            if s2 is None:
-                if n1 == 0:
-                    if s1.buf.strip():
-                        raise FastqFormatError(f"{path1}: truncated FASTQ record at end of file")
+            h1 = r1.next_half()
+            if r2 is None:
+                if h1 is None:
                     return
-                stride = max(4, (l1 + 3) // 4 * 4)
-                yield Chunk(n1, stride, *s1.take(n1, b1, stride))
+                yield Chunk(h1.n, h1.stride, h1.raw, h1.name_off, h1.name_len, h1.seq, h1.qual, h1.lens,
+                            _owned=h1.owned)
+                done += h1.n
                 continue
-            n2, b2, l2 = s2.fill(chunk_reads)
-            n = min(n1, n2)
-            if n == 0:
-                if n1 != n2 or s1.buf.strip() or s2.buf.strip():
-                    raise FastqFormatError(
-                        "Reads are improperly paired! There are more reads in one file than in the other, "
-                        "or a record is truncated.")
+            h2 = r2.next_half()
+            if h1 is None and h2 is None:
                 return
-            if n < n1:
-                n1, b1, l1 = s1.fill(n)
-            if n < n2:
-                n2, b2, l2 = s2.fill(n)
-            stride = max(4, (max(l1, l2) + 3) // 4 * 4)
-            a = s1.take(n, b1, stride)
-            b = s2.take(n, b2, stride)
-            yield Chunk(n, stride, *a, *b)
+            if h1 is None or h2 is None or h1.n != h2.n:
+                # both files are cut every chunk_reads records: a difference means unequal record counts
+                raise FastqFormatError(
+                    "Reads are improperly paired! There are more reads in one file than in the other, "
+                    "or a record is truncated.")
+            stride = max(h1.stride, h2.stride)
+            h1, h2 = _restride(path1, h1, stride, done), _restride(path2, h2, stride, done)
+            yield Chunk(h1.n, stride, h1.raw, h1.name_off, h1.name_len, h1.seq, h1.qual, h1.lens,
+                        h2.raw, h2.name_off, h2.name_len, h2.seq, h2.qual, h2.lens, _owned=h1.owned + h2.owned)
+            done += h1.n
     finally:
-        s1.close()
-        if s2:
-            s2.close()
+        r1.close()
+        if r2:
+            r2.close()
 
 
-def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray], res2: Optional[np.ndarray]):
-    """-> (bytes[route][mate], counts[route]) with routes 0 trimmed, 1 short, 2 untrimmed."""
+_tls = threading.local()
+
+
+def _out_buffers(cap_bytes: Sequence[int]):
+    """Six output buffers (route x mate) of this thread, grown on demand and reused between chunks."""
+    bufs = getattr(_tls, "bufs", None)
+    if bufs is None:
+        bufs = _tls.bufs = [[np.empty(0, dtype=np.uint8) for _ in range(2)] for _ in range(3)]
+    for r in range(3):
+        for m in range(2):
+            if bufs[r][m].size < cap_bytes[m]:
+                bufs[r][m] = np.empty(int(cap_bytes[m] * 1.25) + 4096, dtype=np.uint8)
+    return bufs
+
+
+def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray], res2: Optional[np.ndarray],
+                 copy: bool = True):
+    """-> (data[route][mate], counts[route]) with routes 0 trimmed, 1 short, 2 untrimmed.  ``data`` holds
+    ``bytes``; with ``copy=False`` it holds memoryviews into this thread's reusable buffers, valid
+    until the thread formats its next chunk."""
     L = _lib()
     fp = _FormatParams()
     fp.paired = 1 if chunk.paired else 0
@@ -203,12 +370,10 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     if chunk.paired:
         suf2 = [s.encode() for s in plan.r2.name_suffixes] + [None, None]
         fp.suffix2[0], fp.suffix2[1] = suf2[0], suf2[1]
-    # worst case per record: header (<= raw bytes in total) + '_' + two captures (<= 510) + sequence
-    # + quality + "@\n\n+\n\n"
-    per_rec = 2 * chunk.stride + 520
-    cap_bytes = [len(chunk.raw1) + per_rec * chunk.n + 16,
-                 (len(chunk.raw2) + per_rec * chunk.n + 16) if chunk.paired else 16]
-    bufs = [[np.empty(cap_bytes[m], dtype=np.uint8) for m in range(2)] for _ in range(3)]
+    # worst case per record: what the input record held (header, sequence, quality: all inside raw)
+    # + '_' + two captures (<= 510) + "@\n\n+\n\n"
+    cap_bytes = [len(chunk.raw1) + 528 * chunk.n + 16, (len(chunk.raw2) + 528 * chunk.n + 16) if chunk.paired else 16]
+    bufs = _out_buffers(cap_bytes)
     out_ptrs = ((C.c_void_p * 2) * 3)()
     for r in range(3):
         for m in range(2):
@@ -216,36 +381,56 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     out_len = ((C.c_int64 * 2) * 3)()
     counts = (C.c_int64 * 3)()
     rc = L.csh_format_chunk(
-        C.byref(fp), chunk.n, chunk.stride, chunk.raw1, chunk.name_off1.ctypes.data, chunk.name_len1.ctypes.data,
-        chunk.seq1.ctypes.data, chunk.qual1.ctypes.data, res1.ctypes.data,
+        C.byref(fp), chunk.n, chunk.stride, _raw_pointer(chunk.raw1), chunk.name_off1.ctypes.data,
+        chunk.name_len1.ctypes.data, chunk.seq1.ctypes.data, chunk.qual1.ctypes.data, res1.ctypes.data,
         cap2.ctypes.data if cap2 is not None else None,
-        chunk.raw2 if chunk.paired else None,
+        _raw_pointer(chunk.raw2) if chunk.paired else None,
         chunk.name_off2.ctypes.data if chunk.paired else None, chunk.name_len2.ctypes.data if chunk.paired else None,
         chunk.seq2.ctypes.data if chunk.paired else None, chunk.qual2.ctypes.data if chunk.paired else None,
         res2.ctypes.data if res2 is not None else None, out_ptrs, out_len, counts)
     if rc < 0:
         i = int(-rc - 1)
-        n1 = chunk.raw1[chunk.name_off1[i]: chunk.name_off1[i] + chunk.name_len1[i]].decode(errors="replace")
-        n2 = chunk.raw2[chunk.name_off2[i]: chunk.name_off2[i] + chunk.name_len2[i]].decode(errors="replace")
+        n1 = bytes(chunk.raw1[chunk.name_off1[i]: chunk.name_off1[i] + chunk.name_len1[i]]).decode(errors="replace")
+        n2 = bytes(chunk.raw2[chunk.name_off2[i]: chunk.name_off2[i] + chunk.name_len2[i]]).decode(errors="replace")
         raise ValueError(f"Input read IDs not identical: '{n1.split()[0] if n1.split() else n1}' != "
                          f"'{n2.split()[0] if n2.split() else n2}'")
-    data = [[bufs[r][m][: out_len[r][m]].tobytes() for m in range(2)] for r in range(3)]
-    return data, [int(c) for c in counts]
+    views = [[memoryview(bufs[r][m])[: out_len[r][m]] for m in range(2)] for r in range(3)]
+    if copy:
+        return [[bytes(v) for v in row] for row in views], [int(c) for c in counts]
+    return views, [int(c) for c in counts]
+
+
+def finish_chunk(chunk: Chunk, plan, res1, cap2, res2, gz: Sequence[Sequence[Optional[bool]]], level: int = 1):
+    """Worker-thread job of the CLI: format one chunk and turn each wanted stream into the bytes that
+    go to disk (one gzip member, or the plain text).  ``gz[route][mate]`` is True / False for
+    compressed / plain outputs and None where no file is open.  -> (blobs[route][mate], counts)."""
+    views, counts = format_chunk(chunk, plan, res1, cap2, res2, copy=False)
+    blobs = [[None, None] for _ in range(3)]
+    for r in range(3):
+        for m in range(2):
+            if gz[r][m] is None or len(views[r][m]) == 0:
+                continue
+            blobs[r][m] = _gzip_member(views[r][m], level) if gz[r][m] else bytes(views[r][m])
+    return blobs, counts
 
 
 _POOL = None
+
+
+def pool_size() -> int:
+    from .synth import usable_cpus
+    return max(2, usable_cpus(32))
 
 
 def _pool():
     global _POOL
     if _POOL is None:
         from concurrent.futures import ThreadPoolExecutor
-        from .synth import usable_cpus
-        _POOL = ThreadPoolExecutor(max_workers=max(2, usable_cpus(32)))
+        _POOL = ThreadPoolExecutor(max_workers=pool_size())
     return _POOL
 
 
-def _gzip_member(data: bytes, level: int) -> bytes:
+def _gzip_member(data, level: int) -> bytes:
     c = zlib.compressobj(level, zlib.DEFLATED, 31)
     return c.compress(data) + c.flush()
 
@@ -272,7 +457,12 @@ class OutputFile:
                 item = self.q.get()
                 if item is None:
                     break
-                self.fh.write(item.result() if self.gz else item)
+                if isinstance(item, tuple):  # (future of finish_chunk, route, mate)
+                    blob = item[0].result()[0][item[1]][item[2]]
+                    if blob:
+                        self.fh.write(blob)
+                else:
+                    self.fh.write(item.result() if self.gz else item)
         except BaseException as exc:  # pragma: no cover
             self.err = exc
         finally:
@@ -285,6 +475,10 @@ class OutputFile:
             self.q.put(_pool().submit(_gzip_member, data, self.level))
         else:
             self.q.put(data)
+
+    def write_job(self, future, route: int, mate: int):
+        """Queue the (route, mate) stream of a :func:`finish_chunk` job; written when the job is done."""
+        self.q.put((future, route, mate))
 
     def close(self):
         self.q.put(None)

@@ -59,6 +59,13 @@ def account_chunk(totals: dict, tp: TrimPlan, len1: np.ndarray, res1: np.ndarray
         totals["written_bp"][m] += int(span[keep].sum())
 
 
+def merge_totals(into: dict, part: dict) -> None:
+    into["in_pairs"] += part["in_pairs"]
+    for key in ("routes", "in_bp", "out_bp", "written_bp"):
+        for i, v in enumerate(part[key]):
+            into[key][i] += v
+
+
 def first_adapter(chain: Optional[MateChain]):
     """(stat slot, op) of the first AdapterCutter in a mate's chain, or (None, None)."""
     if chain is None:

@@ -209,9 +209,14 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     engines = {}
     stride_cap = {}
     slots_per_engine = 2
-    inflight = deque()  # (engine, slot, chunk, result arrays)
+    inflight = deque()  # (engine, slot, chunk, result arrays): on the GPU
+    finishing = deque()  # futures of fastq.finish_chunk, in chunk order
     totals = report.new_totals()
     t0 = time.perf_counter()
+    # which (route, mate) streams go to disk, and whether they are gzip
+    gz = [[(fh.gz if fh is not None else None) for fh in (group + [None])[:2]] for group in outs]
+    pool = fastq._pool()
+    max_finishing = fastq.pool_size() + 2  # chunks being formatted / compressed (about 90 MB each)
 
     def engine_for(dev, stride):
         eng = engines.get(dev)
@@ -223,18 +228,35 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
             engines[dev], stride_cap[dev] = eng, cap
         return eng
 
+    def finish(chunk, r1, cap2, r2):
+        """Worker thread: records -> bytes on their way to disk; also this chunk's share of the report."""
+        try:
+            blobs, counts = fastq.finish_chunk(chunk, tp, r1, cap2, r2, gz)
+            part = report.new_totals()
+            report.account_chunk(part, tp, chunk.len1, r1, chunk.len2 if paired else None, r2 if paired else None)
+            part["routes"] = counts
+            return blobs, part
+        finally:
+            chunk.release()
+
+    def reap(block: bool):
+        while finishing and (block or finishing[0].done()):
+            _, part = finishing.popleft().result()
+            report.merge_totals(totals, part)
+            block = False
+
     def drain_one():
         eng, slot, chunk, res = inflight.popleft()
         eng.wait(slot)
         r1, cap2, r2 = res
-        data, counts = fastq.format_chunk(chunk, tp, r1, cap2, r2)
+        fut = pool.submit(finish, chunk, r1, cap2, r2)
         for route in range(3):
-            totals["routes"][route] += counts[route]
             for m in range(2 if paired else 1):
                 fh = outs[route][m]
                 if fh is not None:
-                    fh.write(data[route][m])
-        report.account_chunk(totals, tp, chunk.len1, r1, chunk.len2 if paired else None, r2 if paired else None)
+                    fh.write_job(fut, route, m)
+        finishing.append(fut)
+        reap(len(finishing) >= max_finishing)
 
     try:
         k = 0
@@ -246,7 +268,7 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
             while len(inflight) >= len(devices) * slots_per_engine:
                 drain_one()
             # a slot that is still in flight on this engine must be drained before reuse
-            while any(e is engines.get(dev) and s == slot for e, s, _, _ in inflight):
+            while any(e is engines.get(dev) and sl == slot for e, sl, _, _ in inflight):
                 drain_one()
             eng = engine_for(dev, chunk.stride)
             res = eng.submit(slot, chunk.seq1, chunk.qual1, chunk.len1, chunk.seq2, chunk.qual2, chunk.len2)
@@ -254,6 +276,8 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
             k += 1
         while inflight:
             drain_one()
+        while finishing:
+            reap(True)
         stats = [e.stats() for e in engines.values()]
     finally:
         for e in engines.values():
