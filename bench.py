@@ -81,12 +81,19 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the trimming engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the N > 1 path on a one-GPU box: CUTSEQ_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
+    # uses gloo for the barrier / max (RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearsal = os.environ.get("CUTSEQ_BENCH_REHEARSAL") == "1"
+    gpu_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     paired = args.workload == "config3"
     tp = make_plan(args.workload, not args.no_filter)
@@ -111,7 +118,7 @@ def main():
         out2 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
         r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None)
 
-    eng = TrimEngine(tp, device=local_rank, slots=0)
+    eng = TrimEngine(tp, device=gpu_index, slots=0)
     # an explicit (non-default) stream: its handle is what the C ABI launches on, and the
     # torch events below are recorded on the same stream, so they bracket the kernel itself
     stream = torch.cuda.Stream(device=dev)
@@ -143,7 +150,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
