@@ -172,7 +172,9 @@ void cs_engine_destroy(cs_engine *eng);
 /* The hot path, inputs already resident in HBM: ONE fused kernel launch over both mates
  * (replaces the per-read modifier loop inside runner.run(pipeline, ...), run.py:473,794).
  * `stream` is a hipStream_t (NULL = the engine's own stream); asynchronous.
- * r2 == NULL for single-end. */
+ * r2 == NULL for single-end.  An engine's launches must be ordered with respect to each other
+ * (one stream at a time, or event dependencies between streams): they share the engine's tile
+ * counters and statistics block.  Use one engine per concurrent stream. */
 int cs_trim_device(cs_engine *eng, void *stream, const cs_reads *r1, const cs_reads *r2,
                    uint32_t n_reads, uint32_t stride);
 
