@@ -238,3 +238,64 @@ def test_reports_from_oracle_results():
     (a,) = rep["adapters_read1"]
     assert a["five_prime_end"]["sequence"] == op1.sequence and a["three_prime_end"] is None
     assert a["five_prime_end"]["trimmed_lengths"] == []
+
+
+# ---------------------------------------------------------------- threaded reader / worker finisher
+
+
+def test_reader_restrides_when_a_later_chunk_is_longer(tmp_path):
+    """The row stride is shared by the two parser threads and only grows; a half parsed with the
+    smaller stride is parsed again, so both mates of a chunk always agree."""
+    recs1 = [(b"r%d" % i, b"A" * 10, b"I" * 10) for i in range(8)]
+    recs2 = [(b"r%d" % i, b"C" * (10 if i < 6 else 70), b"I" * (10 if i < 6 else 70)) for i in range(8)]
+    p1 = write_fq(tmp_path / "1.fq", recs1, gz=False)
+    p2 = write_fq(tmp_path / "2.fq.gz", recs2, gz=True)
+    chunks = list(fastq.read_chunks(str(p1), str(p2), chunk_reads=3))
+    assert [c.n for c in chunks] == [3, 3, 2]
+    for c in chunks:
+        assert c.seq1.shape == c.seq2.shape == (c.n, c.stride) and c.stride % 4 == 0
+    assert chunks[-1].stride == 72 and util.row_bytes(chunks[-1].seq2, chunks[-1].len2, 1) == b"C" * 70
+    assert util.row_bytes(chunks[-1].seq1, chunks[-1].len1, 1) == b"A" * 10
+    for c in chunks:
+        c.release()
+    # released buffers come back from the arena: same storage for the next chunk of the same shape
+    again = list(fastq.read_chunks(str(p1), str(p2), chunk_reads=3))
+    assert [c.n for c in again] == [3, 3, 2]
+
+
+def test_finish_chunk_and_ordered_writer(tmp_path):
+    """finish_chunk (format + one gzip member per stream) through OutputFile.write_job gives the
+    same decompressed text as the plain formatter, in chunk order, for gz and plain outputs."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    st = planmod.CutadaptConfig()
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    r1p, r2p = str(util.GOLDEN / "fixture1k_R1.fq.gz"), str(util.GOLDEN / "fixture1k_R2.fq.gz")
+    want1, want2, jobs = b"", b"", []
+    outs = [fastq.OutputFile(str(tmp_path / "o1.fq.gz")), fastq.OutputFile(str(tmp_path / "o2.fq"))]
+    gz = [[True, False], [None, None], [None, None]]
+    with ThreadPoolExecutor(4) as pool:
+        for c in fastq.read_chunks(r1p, r2p, chunk_reads=128):
+            batch = SynthLike(c)
+            (r1, cap2, _), (r2, _, _) = util.oracle_run(tp, batch)
+            data, _ = fastq.format_chunk(c, tp, r1, cap2, r2)
+            want1 += data[0][0]
+            want2 += data[0][1]
+            fut = pool.submit(fastq.finish_chunk, c, tp, r1, cap2, r2, gz)
+            outs[0].write_job(fut, 0, 0)
+            outs[1].write_job(fut, 0, 1)
+            jobs.append(fut)
+        for o in outs:
+            o.close()
+    assert gzip.decompress((tmp_path / "o1.fq.gz").read_bytes()) == want1
+    assert (tmp_path / "o2.fq").read_bytes() == want2
+    assert sum(f.result()[1][0] + f.result()[1][1] for f in jobs) == 1000
+
+
+class SynthLike:
+    """The arrays of a fastq.Chunk under the attribute names util.oracle_run expects."""
+
+    def __init__(self, c):
+        self.n, self.stride = c.n, c.stride
+        self.seq1, self.qual1, self.len1 = c.seq1, c.qual1, c.len1
+        self.seq2, self.qual2, self.len2 = c.seq2, c.qual2, c.len2
