@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["config3", "config2"], default="config3")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
+    ap.add_argument("--no-copy-probe", action="store_true", help="skip the HBM copy-bandwidth probe")
     ap.add_argument("--traffic-json", type=str, default=str(ROOT / "profiles" / "r01_pmc_summary.json"),
                     help="JSON with HBM bytes per launch measured in separate rocprofv3 --pmc passes (tools/pmc.sh)")
     return ap.parse_args()
@@ -203,6 +204,27 @@ def main():
         "exact_dp_fraction": round((st1.n_exact_dp + st2.n_exact_dp) / max(1, st1.n_reads + st2.n_reads), 4),
     }
 
+    if rank == 0 and world == 1 and not args.no_copy_probe:
+        # measured HBM copy bandwidth of this box: a second denominator next to the 8 TB/s spec
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        src.fill_(7)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbps = 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9  # read + write
+        result["roofline"]["copy_measured_GBps"] = round(copy_gbps, 1)
+        result["roofline"]["frac_of_copy_measured"] = round(achieved / copy_gbps, 5)
+        del src, dst
+
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle  # the checker, timed as the CPU baseline; never part of the product path
         m = min(args.cpu_sample, n)
@@ -226,7 +248,8 @@ def main():
             "cores": threads,
             "kind": "port",
             "sample": f"first {m} {'pairs' if paired else 'reads'} of the same batch, own scalar C restatement "
-                      f"(oracle/cutseq_oracle.c), {threads} threads, {cpu_s:.2f} s; cutadapt is not installable here",
+                      f"(oracle/cutseq_oracle.c), {threads} threads, {cpu_s:.2f} s wall = {cpu_s * threads:.0f} CPU-seconds; "
+                      "cutadapt is not installable here",
             "gpu_results_identical_on_sample": same,
         }
         if not same:
