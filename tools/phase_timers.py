@@ -63,4 +63,7 @@ for mate, s in enumerate(stats):
     print(f"mate {mate + 1}: {tot / 1e9:.3f} G wave-cycles")
     for i, name in enumerate(PHASES):
         print(f"  {100 * t[i] / tot:5.1f} %   {name}")
+    passes, steps, items = (int(s.op_matched[13 + i]) for i in range(3))
+    print(f"  strip passes {passes} ({passes / (n / 64):.2f} per tile), {steps / max(passes, 1):.1f} steps and "
+          f"{items / max(passes, 1):.1f} survivors per pass")
 eng.close()
