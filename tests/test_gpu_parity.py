@@ -336,3 +336,23 @@ def test_engine_reuse_and_concurrent_engines():
             e.close()
     with TrimEngine(tp_a, slots=0):  # slots are released on close
         pass
+
+
+def test_device_reproduces_frozen_result_checksums():
+    """The committed CRC-32 values of the oracle's results on a seeded 200k-pair batch
+    (tests/golden/synth_results_crc.json): the device path without the oracle in the loop."""
+    import json
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import make_results_golden as g
+
+    def device_results(tp, batch):
+        with TrimEngine(tp, device=0, slots=1, max_reads=batch.n, max_stride=batch.stride) as eng:
+            r1, _, r2 = eng.trim(batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2)
+        return r1, r2
+
+    for case in json.loads((util.GOLDEN / "synth_results_crc.json").read_text()):
+        got = g.crc_case(case["scheme"], case["flags"], case["rule"], device_results)
+        assert (got["crc_r1"], got["crc_r2"]) == (case["crc_r1"], case["crc_r2"]), case

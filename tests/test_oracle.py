@@ -362,3 +362,20 @@ def test_fixture_subset_plumbing():
     # a good share of R1 carries the 3' adapter (~27-33 %)
     frac = s1.op_matched[1] / 1000
     assert 0.2 < frac < 0.6
+
+
+def test_oracle_reproduces_frozen_result_checksums():
+    """tests/golden/synth_results_crc.json (tools/make_results_golden.py): CRC-32 of the per-read
+    results on a seeded 200k-pair batch; guards the oracle (and the synthetic generator) against drift."""
+    import json
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import make_results_golden as g
+
+    frozen = json.loads((util.GOLDEN / "synth_results_crc.json").read_text())
+    assert len(frozen) == len(g.CASES)
+    case = frozen[0]  # one case on the CPU (the GPU suite checks all of them on the device)
+    got = g.crc_case(case["scheme"], case["flags"], case["rule"], g.oracle_results)
+    assert (got["crc_r1"], got["crc_r2"]) == (case["crc_r1"], case["crc_r2"])
