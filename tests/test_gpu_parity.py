@@ -356,3 +356,52 @@ def test_device_reproduces_frozen_result_checksums():
     for case in json.loads((util.GOLDEN / "synth_results_crc.json").read_text()):
         got = g.crc_case(case["scheme"], case["flags"], case["rule"], device_results)
         assert (got["crc_r1"], got["crc_r2"]) == (case["crc_r1"], case["crc_r2"]), case
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fuzz_odd_alphabets_qualities_and_lengths(seed):
+    """Reads nobody should feed a trimmer but somebody will: lower case, IUPAC codes, dots, every
+    printable quality character, lengths from 0 up, adapters planted with random damage -- through
+    randomly drawn presets and flags, device against oracle."""
+    rng = random.Random(1000 + seed)
+    presets = sorted(BUILDIN_ADAPTERS) + [
+        "ACACGACGCTCTTCCGATCT(ATCACG)NNNNNNNNXX<XXXNNNN(CGATGT)AGATCGGAAGAGCACACGTC",
+        "ACGTACGTACGTAC(GATTACA)NN>XNN(TGCA)GGCCTTAAGGCCAATT", "AAGCAGTGGTATCAACGCAGAGTACXXXXXX-NNNNNNNNCTGTCTCTTATACACATCT"]
+    alphabets = ["ACGT", "ACGTN", "ACGTacgt", "ACGTNRYKMSWBDHV", "ACGT.", "AAAAAAAC", "TTTTTTTG"]
+    for round_ in range(8):
+        name = rng.choice(presets)
+        scheme = BUILDIN_ADAPTERS.get(name, name)
+        bc = BarcodeConfig(scheme)
+        st = planmod.CutadaptConfig()
+        st.trim_polyA = rng.random() < 0.7
+        st.trim_polyA_wo_direction = rng.random() < 0.3
+        st.conditional_cutter = rng.random() < 0.7
+        st.force_anywhere = rng.random() < 0.3
+        st.ensure_inline_barcode = rng.random() < 0.5
+        st.min_length = rng.choice([0, 1, 20, 35, 151])
+        st.min_quality = rng.choice([0, 2, 20, 30, 41, 93])
+        st.force_trim_min_length = rng.choice([0, 50, 120, 10000])
+        st.select_rule = rng.choice([0, 1])
+        paired = rng.random() < 0.7
+        pieces = [bc.p5.fw, bc.p7.fw, bc.p5.rc, bc.p7.rc, "A" * 30, "T" * 30]
+        reads1, reads2 = [], []
+        for _ in range(1200):
+            pair = []
+            for _mate in range(2):
+                alpha = rng.choice(alphabets)
+                parts = []
+                for _ in range(rng.randint(0, 4)):
+                    if rng.random() < 0.5:
+                        parts.append(util.random_dna(rng, rng.randint(0, 60), alpha))
+                    else:
+                        piece = rng.choice(pieces)
+                        piece = piece[rng.randint(0, len(piece) // 2):][: rng.randint(1, len(piece))]
+                        parts.append(util.mutate(rng, piece, rng.randint(0, 3), alpha))
+                seq = "".join(parts)[: rng.choice([0, 1, 7, 19, 20, 21, 50, 149, 150, 151, 155])]
+                qual = "".join(chr(rng.randint(33, 126)) for _ in seq)
+                pair.append((seq, qual))
+            reads1.append(pair[0])
+            reads2.append(pair[1])
+        batch = util.batch_from_reads(reads1, reads2 if paired else None)
+        tp = util.compile_plan(scheme, st, paired, untrimmed_requested=rng.random() < 0.3)
+        run_both(tp, batch)
