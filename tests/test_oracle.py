@@ -379,3 +379,59 @@ def test_oracle_reproduces_frozen_result_checksums():
     case = frozen[0]  # one case on the CPU (the GPU suite checks all of them on the device)
     got = g.crc_case(case["scheme"], case["flags"], case["rule"], g.oracle_results)
     assert (got["crc_r1"], got["crc_r2"]) == (case["crc_r1"], case["crc_r2"])
+
+
+@pytest.mark.parametrize("seed", list(range(1, 11)))
+def test_fuzz_c_oracle_vs_string_pipeline_on_odd_inputs(seed):
+    """The two restatements (C on intervals + native-style formatter vs Python on strings) on reads
+    with lower case, IUPAC codes, dots, arbitrary printable qualities and awkward lengths, through
+    randomly drawn schemes and flags."""
+    rng = random.Random(7000 + seed)
+    presets = sorted(BUILDIN_ADAPTERS) + [
+        "ACACGACGCTCTTCCGATCT(ATCACG)NNNNNNNNXX<XXXNNNN(CGATGT)AGATCGGAAGAGCACACGTC",
+        "ACGTACGTACGTAC(GATTACA)NN>XNN(TGCA)GGCCTTAAGGCCAATT"]
+    alphabets = ["ACGT", "ACGTN", "ACGTacgt", "ACGTNRYKMSWBDHV", "ACGT.", "AAAAAAAC", "TTTTTTTG"]
+    for _round in range(3):
+        name = rng.choice(presets)
+        scheme = BUILDIN_ADAPTERS.get(name, name)
+        bc = BarcodeConfig(scheme)
+        st = planmod.CutadaptConfig()
+        st.trim_polyA = rng.random() < 0.7
+        st.trim_polyA_wo_direction = rng.random() < 0.3
+        st.conditional_cutter = rng.random() < 0.7
+        st.force_anywhere = rng.random() < 0.3
+        st.ensure_inline_barcode = rng.random() < 0.5
+        st.auto_rc = rng.random() < 0.3
+        st.min_length = rng.choice([0, 1, 20, 35])
+        st.min_quality = rng.choice([0, 2, 20, 30, 41])
+        st.select_rule = rng.choice([0, 1])
+        paired = rng.random() < 0.6
+        pieces = [bc.p5.fw, bc.p7.fw, bc.p5.rc, bc.p7.rc, "A" * 30, "T" * 30]
+        reads1, reads2 = [], []
+        for _ in range(250):
+            pair = []
+            for _mate in range(2):
+                alpha = rng.choice(alphabets)
+                parts = []
+                for _ in range(rng.randint(0, 4)):
+                    if rng.random() < 0.5:
+                        parts.append(util.random_dna(rng, rng.randint(0, 50), alpha))
+                    else:
+                        piece = rng.choice(pieces)
+                        piece = piece[rng.randint(0, len(piece) // 2):][: rng.randint(1, len(piece))]
+                        parts.append(util.mutate(rng, piece, rng.randint(0, 3), alpha))
+                seq = "".join(parts)[: rng.choice([0, 1, 7, 19, 20, 21, 50, 101, 150])]
+                qual = "".join(chr(rng.randint(33, 126)) for _ in seq)
+                pair.append((seq, qual))
+            reads1.append(pair[0])
+            reads2.append(pair[1])
+        batch = util.batch_from_reads(reads1, reads2 if paired else None)
+        names1 = [f"r{i} c".encode() for i in range(batch.n)]
+        names2 = [f"r{i} d".encode() for i in range(batch.n)]
+        untrimmed_requested = rng.random() < 0.3
+        tp = util.compile_plan(scheme, st, paired, untrimmed_requested)
+        (res1, cap2, _), m2 = util.oracle_run(tp, batch)
+        got = util.format_batch(tp, batch, names1, names2, res1, cap2, m2[0] if m2 else None)
+        want = util.pyref_run(scheme, st, batch, names1, names2 if paired else None, untrimmed_requested)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g == w, (name, i, g, w)
