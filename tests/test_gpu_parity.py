@@ -405,3 +405,29 @@ def test_fuzz_odd_alphabets_qualities_and_lengths(seed):
         batch = util.batch_from_reads(reads1, reads2 if paired else None)
         tp = util.compile_plan(scheme, st, paired, untrimmed_requested=rng.random() < 0.3)
         run_both(tp, batch)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_full_hit_inside_plus_partial_hit_at_the_end(rule, use_filter):
+    """Every read carries a damaged full-length adapter somewhere and an adapter prefix (exact or with
+    an error) at its very end, at every distance from each other -- the case where the filter may drop
+    the end-of-read rows (leftmost rule, far apart) or must keep them (score rule, or close together).
+    All 64 lanes of a wave need the exact DP here, so the strip passes run four deep."""
+    rng = random.Random(41 + rule)
+    ad = "AGATCGGAAGAGCACACGTC"
+    reads = []
+    for _ in range(4000):
+        head = util.random_dna(rng, rng.randint(0, 60))
+        hit = util.mutate(rng, ad, rng.randint(0, 4))
+        gap = util.random_dna(rng, rng.choice([0, 1, 2, 3, 5, 8, 9, 10, 11, 12, 15, 20, 30, 40, 70]))
+        tail = util.mutate(rng, ad[: rng.randint(3, 19)], rng.choice([0, 0, 1, 1, 2]))
+        s = (head + hit + gap + tail)[:200]
+        reads.append((s, "I" * len(s)))
+    for where, mo, shortcut in (("BACK", 3, 1), ("ANYWHERE", 3, 1), ("BACK", 10, 0)):
+        tp = one_adapter_plan(ad, 0.2, mo, WHERE[where], abi.CS_REMOVE_AFTER, False, shortcut, rule, use_filter)
+        run_both(tp, util.batch_from_reads(reads), threads=8)
+    # the same through the reversed aligner (RightmostFrontAdapter)
+    rev = [(s[::-1], q) for s, q in reads]
+    tp = one_adapter_plan(ad[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, True, 1, rule, use_filter)
+    run_both(tp, util.batch_from_reads(rev), threads=8)
