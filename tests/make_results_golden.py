@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Freeze the oracle's results on a seeded synthetic batch as CRC-32 values (tests/golden/synth_results_crc.json).
+"""(python tests/make_results_golden.py)  Freeze the oracle's results on a seeded synthetic batch as CRC-32 values (tests/golden/synth_results_crc.json).
 The CPU suite checks the oracle still reproduces them, the GPU suite checks the device does: a change to
 either side that alters results is caught even when both change together."""
 import json
@@ -9,7 +9,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "tests"))  # lives under tests/: it drives the oracle, which only tests may do
 import util  # noqa: E402
 from cutseq_amd import plan as planmod, synth  # noqa: E402
 from cutseq_amd.common import BUILDIN_ADAPTERS  # noqa: E402

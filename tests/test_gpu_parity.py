@@ -345,7 +345,6 @@ def test_device_reproduces_frozen_result_checksums():
     import sys
     from pathlib import Path
 
-    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
     import make_results_golden as g
 
     def device_results(tp, batch):

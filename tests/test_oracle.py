@@ -365,13 +365,12 @@ def test_fixture_subset_plumbing():
 
 
 def test_oracle_reproduces_frozen_result_checksums():
-    """tests/golden/synth_results_crc.json (tools/make_results_golden.py): CRC-32 of the per-read
+    """tests/golden/synth_results_crc.json (tests/make_results_golden.py): CRC-32 of the per-read
     results on a seeded 200k-pair batch; guards the oracle (and the synthetic generator) against drift."""
     import json
     import sys
     from pathlib import Path
 
-    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
     import make_results_golden as g
 
     frozen = json.loads((util.GOLDEN / "synth_results_crc.json").read_text())
