@@ -55,7 +55,20 @@ def tier_e(n=2_000_000):
                         "-A", "TAKARAV3", "--trim-polyA", "-O", f"{d}/out"], check=True, cwd=str(ROOT),
                        stderr=subprocess.DEVNULL)
         dt = time.perf_counter() - t0
-    return {"pairs": n, "seconds": dt, "M_pairs_per_s": n / dt / 1e6}
+        out = {"pairs": n, "seconds": dt, "M_pairs_per_s": n / dt / 1e6}
+        # the same run on uncompressed text in and out (no codec on either side)
+        import gzip
+        import shutil
+        for m in (1, 2):
+            with gzip.open(f"{d}/syn_R{m}.fastq.gz", "rb") as src, open(f"{d}/plain_R{m}.fastq", "wb") as dst:
+                shutil.copyfileobj(src, dst, 1 << 24)
+        t0 = time.perf_counter()
+        subprocess.run([sys.executable, "-m", "cutseq_amd.run", f"{d}/plain_R1.fastq", f"{d}/plain_R2.fastq",
+                        "-A", "TAKARAV3", "--trim-polyA", "-o", f"{d}/o1.fastq", f"{d}/o2.fastq",
+                        "-s", f"{d}/s1.fastq", f"{d}/s2.fastq"], check=True, cwd=str(ROOT), stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+        out["plain_text"] = {"seconds": dt, "M_pairs_per_s": n / dt / 1e6}
+    return out
 
 
 if __name__ == "__main__":
