@@ -9,13 +9,12 @@ from __future__ import annotations
 
 import ctypes as C
 import gzip
-import io
 import queue
 import threading
 import zlib
 from dataclasses import dataclass
 from pathlib import Path
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import numpy as np
 

@@ -7,7 +7,7 @@ filter steps (run.py:446-471, 763-792) and dnaio's FASTQ writer.  It consumes th
 """
 from __future__ import annotations
 
-from typing import Iterable, Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 from . import abi
 

@@ -12,7 +12,7 @@ describe the FIRST AdapterCutter of each mate's chain.
 from __future__ import annotations
 
 import json
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 
