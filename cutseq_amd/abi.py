@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-CS_ABI_VERSION = 1
+CS_ABI_VERSION = 2
 CS_MAX_ADAPTER = 128
 CS_MAX_OPS = 24
 CS_MAX_STRIDE = 1536
@@ -26,6 +26,8 @@ CS_WHERE_ANYWHERE = 15
 CS_REMOVE_BEFORE, CS_REMOVE_AFTER = 0, 1
 CS_SHORTCUT_NONE, CS_SHORTCUT_FIND = 0, 1
 CS_SELECT_LEFTMOST, CS_SELECT_SCORE = 0, 1
+CS_CASE_FOLD, CS_CASE_SENSITIVE = 0, 1
+CS_TIE_INSERTION, CS_TIE_DELETION = 0, 1
 
 CS_F_ADAPTER5 = 0x01
 CS_F_ADAPTER3 = 0x02
@@ -71,7 +73,10 @@ class cs_params(C.Structure):
         ("min_length", C.c_uint16),
         ("select_rule", C.c_uint8),
         ("use_filter", C.c_uint8),
-        ("reserved", C.c_uint32 * 6),
+        ("case_rule", C.c_uint8),
+        ("indel_tie", C.c_uint8),
+        ("reserved8", C.c_uint8 * 2),
+        ("reserved", C.c_uint32 * 5),
     ]
 
 

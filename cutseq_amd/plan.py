@@ -39,8 +39,12 @@ class CutadaptConfig:
         self.json_file = None
         self.force_trim_min_length = 50
         self.force_anywhere = False
-        # not in the reference: which cutadapt generation's candidate selection to follow
-        self.select_rule = abi.CS_SELECT_LEFTMOST
+        # not in the reference: the cutadapt rules this build restates from recollection, one switch
+        # each (tools/parity_exposure.py counts what every switch changes)
+        self.select_rule = abi.CS_SELECT_LEFTMOST  # cutadapt >= 4.0 candidate selection
+        self.shortcut = abi.CS_SHORTCUT_NONE       # cutadapt >= 3: no str.find before the aligner
+        self.case_rule = abi.CS_CASE_FOLD          # match_to aligns sequence.upper()
+        self.indel_tie = abi.CS_TIE_INSERTION      # SURVEY appendix B.2 order
 
 
 @dataclass
@@ -148,6 +152,8 @@ class TrimPlan:
     reverse_complement: bool = False  # single-end --auto-rc on a '-' library
     select_rule: int = abi.CS_SELECT_LEFTMOST
     use_filter: bool = True
+    case_rule: int = abi.CS_CASE_FOLD
+    indel_tie: int = abi.CS_TIE_INSERTION
 
     @property
     def paired(self) -> bool:
@@ -163,6 +169,8 @@ class TrimPlan:
         p.min_length = max(0, min(int(self.min_length), 0xFFFF))
         p.select_rule = self.select_rule
         p.use_filter = 1 if self.use_filter else 0
+        p.case_rule = self.case_rule
+        p.indel_tie = self.indel_tie
         return p
 
     def pack(self):
@@ -215,15 +223,15 @@ def pack_ops(ops: Sequence[Op]):
 # ---- adapter factories, one per cutadapt class the reference uses (run.py:17-24) ----
 
 
-def rightmost_front(seq, rate, min_overlap, flag=0):
+def rightmost_front(seq, rate, min_overlap, flag=0, shortcut=abi.CS_SHORTCUT_NONE):
     return AdapterOp("RightmostFrontAdapter", seq, rate, min_overlap, abi.CS_WHERE_BACK,
-                     abi.CS_REMOVE_BEFORE, rightmost=True, shortcut=abi.CS_SHORTCUT_FIND, match_flag=flag)
+                     abi.CS_REMOVE_BEFORE, rightmost=True, shortcut=shortcut, match_flag=flag)
 
 
-def back(seq, rate, min_overlap, force_anywhere=False, flag=0):
+def back(seq, rate, min_overlap, force_anywhere=False, flag=0, shortcut=abi.CS_SHORTCUT_NONE):
     where = abi.CS_WHERE_ANYWHERE if force_anywhere else abi.CS_WHERE_BACK
     return AdapterOp("BackAdapter", seq, rate, min_overlap, where, abi.CS_REMOVE_AFTER,
-                     shortcut=abi.CS_SHORTCUT_FIND, match_flag=flag)
+                     shortcut=shortcut, match_flag=flag)
 
 
 def prefix(seq, rate, flag=0, required=False):
@@ -261,8 +269,9 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     ) or untrimmed_requested  # run.py:453-456
     ops: List[Op] = []
     # step 2 / 3: 5' template-switch artefact, 3' read-through
-    ops.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5))
-    ops.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3))
+    sc = getattr(settings, "shortcut", abi.CS_SHORTCUT_NONE)
+    ops.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5, sc))
+    ops.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4: inline barcodes
     if barcode.inline5.len > 0:
         ops.append(prefix(barcode.inline5.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
@@ -308,6 +317,8 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
         untrimmed_filter=untrimmed_filter,
         reverse_complement=rc,
         select_rule=getattr(settings, "select_rule", abi.CS_SELECT_LEFTMOST),
+        case_rule=getattr(settings, "case_rule", abi.CS_CASE_FOLD),
+        indel_tie=getattr(settings, "indel_tie", abi.CS_TIE_INSERTION),
     )
 
 
@@ -321,11 +332,12 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     o1: List[Op] = []
     o2: List[Op] = []
     # step 2
-    o1.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5))
-    o2.append(rightmost_front(barcode.p7.rc, MAX_ERRORS, 10, abi.CS_F_ADAPTER5))
+    sc = getattr(settings, "shortcut", abi.CS_SHORTCUT_NONE)
+    o1.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5, sc))
+    o2.append(rightmost_front(barcode.p7.rc, MAX_ERRORS, 10, abi.CS_F_ADAPTER5, sc))
     # step 3
-    o1.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3))
-    o2.append(back(barcode.p5.rc, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3))
+    o1.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
+    o2.append(back(barcode.p5.rc, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4
     if barcode.inline5.len > 0:
         o1.append(prefix(barcode.inline5.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
@@ -378,6 +390,8 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
         untrimmed_filter=untrimmed_filter,
         swap_outputs=swap,
         select_rule=getattr(settings, "select_rule", abi.CS_SELECT_LEFTMOST),
+        case_rule=getattr(settings, "case_rule", abi.CS_CASE_FOLD),
+        indel_tie=getattr(settings, "indel_tie", abi.CS_TIE_INSERTION),
     )
 
 

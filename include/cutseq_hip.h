@@ -11,7 +11,8 @@
  * Data contract
  *   A batch is a structure-of-arrays of reads: `seq` and `qual` are row-major byte
  *   matrices [n_reads][stride] (ASCII as in the FASTQ record, stride a multiple of 4,
- *   bytes past len[i] are ignored), `len` holds the read lengths (<= stride).
+ *   bytes past len[i] are ignored), `len` holds the read lengths.  len[i] <= stride is the
+ *   caller's contract; the kernel clamps a longer value to stride instead of reading past the row.
  *   Headers never cross the boundary: the device returns, per read, the surviving
  *   interval of the ORIGINAL record plus the location of the captured UMI, and the
  *   host renames/formats (cutadapt's Renamer is string work).
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2
 #define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
 #define CS_MAX_OPS 24      /* longest per-mate op chain                           */
 #define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
@@ -56,13 +57,26 @@ enum {
   CS_WHERE_ANYWHERE = 15            /* BackAdapter(force_anywhere=True)              */
 };
 enum { CS_REMOVE_BEFORE = 0, CS_REMOVE_AFTER = 1 };
-/* exact-substring short cut taken before the aligner (BackAdapter/FrontAdapter.match_to:
- * str.find, RightmostFrontAdapter.match_to: str.rfind) */
+/* Exact-substring short cut taken before the aligner.  CS_SHORTCUT_NONE (the default of every
+ * op cutseq_amd/plan.py compiles) follows cutadapt >= 3: <Adapter>.match_to goes straight to
+ * Aligner.locate (behind a result-neutral k-mer filter).  CS_SHORTCUT_FIND restates cutadapt <= 2.x
+ * (str.find / str.rfind first) and is kept as an opt-in so its exposure can be measured
+ * (tools/parity_exposure.py). */
 enum { CS_SHORTCUT_NONE = 0, CS_SHORTCUT_FIND = 1 };
 /* which candidate wins inside Aligner.locate */
 enum {
   CS_SELECT_LEFTMOST = 0, /* cutadapt >= 4.0: first hit, replaced only by an overlapping/longer hit of higher score */
   CS_SELECT_SCORE = 1     /* cutadapt 3.x / SURVEY.md appendix B.2: highest score, then fewest errors           */
+};
+
+/* read bases as the aligner sees them: <Adapter>.match_to aligns sequence.upper() while the
+ * output keeps the original bytes */
+enum { CS_CASE_FOLD = 0, CS_CASE_SENSITIVE = 1 };
+/* Aligner.locate on a mismatching cell whose insertion (same column, row above) and deletion (same
+ * row, previous column) cost the same and less than the diagonal: which one supplies origin/score */
+enum {
+  CS_TIE_INSERTION = 0, /* `elif cost_insertion <= cost_deletion` first */
+  CS_TIE_DELETION = 1   /* the other order */
 };
 
 /* per-read result flag bits */
@@ -106,7 +120,10 @@ typedef struct cs_params {
   uint16_t min_length;   /* TooShort threshold (-m, run.py:943-948)           */
   uint8_t select_rule;   /* CS_SELECT_*                                       */
   uint8_t use_filter;    /* 1 = bit-parallel pre-filter + windowed DP (result-neutral), 0 = full DP */
-  uint32_t reserved[6];
+  uint8_t case_rule;     /* CS_CASE_*  (0 = fold, the cutadapt behaviour)         */
+  uint8_t indel_tie;     /* CS_TIE_*                                          */
+  uint8_t reserved8[2];
+  uint32_t reserved[5];
 } cs_params;
 
 /* 8 bytes per read: [start, stop) of the ORIGINAL record survives; cap_* locates the

@@ -34,9 +34,9 @@ def lib() -> C.CDLL:
     if _LIB is None:
         so = build()
         L = C.CDLL(str(so))
-        L.cs_oracle_locate.restype = C.c_int
-        L.cs_oracle_locate.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int,
-                                       C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 6)]
+        L.cs_oracle_locate2.restype = C.c_int
+        L.cs_oracle_locate2.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 6)]
         L.cs_oracle_quality_trim_index.restype = C.c_int
         L.cs_oracle_quality_trim_index.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.cs_oracle_trim_mt.restype = C.c_int
@@ -48,13 +48,13 @@ def lib() -> C.CDLL:
 
 
 def locate(ref: str, query: str, max_error_rate: float, flags: int, min_overlap: int = 1,
-           select_rule: int = abi.CS_SELECT_LEFTMOST):
+           select_rule: int = abi.CS_SELECT_LEFTMOST, indel_tie: int = abi.CS_TIE_INSERTION):
     """Aligner.locate through the C restatement -> tuple or None."""
     m = len(ref)
     thr = (C.c_uint8 * (m + 1))(*[int(L * max_error_rate) for L in range(m + 1)])
     out = (C.c_int * 6)()
-    hit = lib().cs_oracle_locate(ref.encode(), m, query.encode(), len(query), thr, int(max_error_rate * m),
-                                 flags, min(min_overlap, m), select_rule, C.byref(out))
+    hit = lib().cs_oracle_locate2(ref.encode(), m, query.encode(), len(query), thr, int(max_error_rate * m),
+                                  flags, min(min_overlap, m), select_rule, indel_tie, C.byref(out))
     return tuple(out) if hit else None
 
 

@@ -67,8 +67,8 @@ static int better_candidate(int select_rule, int m, int n, const match_t *best, 
  * thr[L] = floor(L * max_error_rate) stands for `cost <= L * max_error_rate`.
  * out = (ref_start, ref_stop, query_start, query_stop, score, errors); returns 1 on a hit.
  */
-int cs_oracle_locate(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *thr, int k,
-                     int flags, int min_overlap, int select_rule, int out[6]) {
+int cs_oracle_locate2(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *thr, int k,
+                      int flags, int min_overlap, int select_rule, int indel_tie, int out[6]) {
   const int start_in_ref = flags & CS_REF_START, start_in_query = flags & CS_QUERY_START;
   const int stop_in_ref = flags & CS_REF_END, stop_in_query = flags & CS_QUERY_STOP;
   entry_t column[CS_MAX_ADAPTER + 1];
@@ -125,14 +125,16 @@ int cs_oracle_locate(const uint8_t *ref, int m, const uint8_t *query, int n, con
           cost = cost_diag;
           origin = diag.origin;
           score = diag.score + MISMATCH_SCORE;
-        } else if (cost_deletion <= cost_insertion) {
-          cost = cost_deletion;
-          origin = column[i].origin;
-          score = column[i].score + DELETION_SCORE;
-        } else {
+        } else if (indel_tie == CS_TIE_INSERTION ? cost_insertion <= cost_deletion
+                                                  : cost_insertion < cost_deletion) {
+          /* SURVEY.md appendix B.2 order: insertion wins the tie (CS_TIE_DELETION: it loses) */
           cost = cost_insertion;
           origin = column[i - 1].origin;
           score = column[i - 1].score + INSERTION_SCORE;
+        } else {
+          cost = cost_deletion;
+          origin = column[i].origin;
+          score = column[i].score + DELETION_SCORE;
         }
       }
       diag = column[i];
@@ -194,6 +196,12 @@ int cs_oracle_locate(const uint8_t *ref, int m, const uint8_t *query, int n, con
   return 1;
 }
 
+/* the SURVEY appendix B.2 tie order, kept under the old name for callers that do not care */
+int cs_oracle_locate(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *thr, int k,
+                     int flags, int min_overlap, int select_rule, int out[6]) {
+  return cs_oracle_locate2(ref, m, query, n, thr, k, flags, min_overlap, select_rule, CS_TIE_INSERTION, out);
+}
+
 /* str.find: leftmost exact occurrence of pat in text, -1 if none */
 static int find_exact(const uint8_t *text, int n, const uint8_t *pat, int m) {
   for (int p = 0; p + m <= n; p++)
@@ -202,20 +210,29 @@ static int find_exact(const uint8_t *text, int n, const uint8_t *pat, int m) {
 }
 
 /*
- * cutadapt adapters.py  <Adapter>.match_to(sequence) for the six classes cutseq uses.
- *   BackAdapter / FrontAdapter : exact str.find first, else Aligner.locate
- *   RightmostFrontAdapter      : str.rfind first, else locate(reversed) and map back
- *   Prefix/Suffix/NonInternal* : Aligner.locate only
+ * cutadapt adapters.py  <Adapter>.match_to(sequence) for the six classes cutseq uses:
+ *   every class           : Aligner.locate(sequence.upper())  (the k-mer finder in front of it is
+ *                           result-neutral); RightmostFrontAdapter locates the reversed adapter in
+ *                           the reversed read and maps the coordinates back
+ *   op->shortcut == FIND  : cutadapt <= 2.x, str.find / str.rfind first (opt-in, not the default)
+ *   params->case_rule     : CS_CASE_SENSITIVE skips the upper() (opt-in, not the default)
  * `op->seq` is already reversed for the rightmost variant, so find-on-reversed == rfind.
  * Returns 1 and (rstart, rstop) in forward read coordinates.
  */
-int cs_oracle_match(const cs_op *op, int select_rule, const uint8_t *read, int n, int *rstart, int *rstop) {
-  uint8_t rev[65536];
+static uint8_t ascii_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+int cs_oracle_match2(const cs_op *op, const cs_params *params, const uint8_t *read, int n, int *rstart,
+                     int *rstop) {
+  uint8_t buf[65536];
   const uint8_t *q = read;
+  const int select_rule = params->select_rule, fold = params->case_rule == CS_CASE_FOLD;
   int m = op->m, qs, qe, hit = 0;
-  if (op->reversed) {
-    for (int i = 0; i < n; i++) rev[i] = read[n - 1 - i];
-    q = rev;
+  if (op->reversed || fold) {
+    for (int i = 0; i < n; i++) {
+      uint8_t c = read[op->reversed ? n - 1 - i : i];
+      buf[i] = fold ? ascii_upper(c) : c;
+    }
+    q = buf;
   }
   if (op->shortcut == CS_SHORTCUT_FIND) {
     int pos = find_exact(q, n, op->seq, m);
@@ -227,7 +244,8 @@ int cs_oracle_match(const cs_op *op, int select_rule, const uint8_t *read, int n
   }
   if (!hit) {
     int out[6];
-    if (!cs_oracle_locate(op->seq, m, q, n, op->thr, op->k, op->align_flags, op->min_overlap, select_rule, out))
+    if (!cs_oracle_locate2(op->seq, m, q, n, op->thr, op->k, op->align_flags, op->min_overlap, select_rule,
+                           params->indel_tie, out))
       return 0;
     qs = out[2];
     qe = out[3];
@@ -240,6 +258,13 @@ int cs_oracle_match(const cs_op *op, int select_rule, const uint8_t *read, int n
     *rstop = qe;
   }
   return 1;
+}
+
+int cs_oracle_match(const cs_op *op, int select_rule, const uint8_t *read, int n, int *rstart, int *rstop) {
+  cs_params p;
+  memset(&p, 0, sizeof p);
+  p.select_rule = (uint8_t)select_rule;
+  return cs_oracle_match2(op, &p, read, n, rstart, rstop);
 }
 
 /* cutadapt qualtrim.pyx quality_trim_index(qualities, cutoff_front=0, cutoff_back, base):
@@ -271,7 +296,7 @@ void cs_oracle_trim_read(const cs_op *ops, int n_ops, const cs_params *params, c
     int n = e - s;
     if (op->kind == CS_OP_ADAPTER) {
       int rstart, rstop;
-      if (cs_oracle_match(op, params->select_rule, seq + s, n, &rstart, &rstop)) {
+      if (cs_oracle_match2(op, params, seq + s, n, &rstart, &rstop)) {
         n_matches++; /* info.matches.append(match) */
         flags |= op->match_flag;
         if (st) st->op_matched[op->stat_slot]++;

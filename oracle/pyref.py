@@ -31,13 +31,17 @@ BACK_NOT_INTERNAL = QUERY_START | REF_END
 ANYWHERE = 15
 
 SELECT_LEFTMOST, SELECT_SCORE = 0, 1
+TIE_INSERTION, TIE_DELETION = 0, 1
+CASE_FOLD, CASE_SENSITIVE = 0, 1
+SHORTCUT_NONE, SHORTCUT_FIND = 0, 1
 
 
 class Aligner:
     """Semi-global unit-cost DP with (cost, score, origin) cells and an error-rate budget."""
 
     def __init__(self, reference: str, max_error_rate: float, flags: int, min_overlap: int = 1,
-                 select_rule: int = SELECT_LEFTMOST):
+                 select_rule: int = SELECT_LEFTMOST, indel_tie: int = TIE_INSERTION):
+        self.indel_tie = indel_tie
         self.reference = reference
         self.m = len(reference)
         self.max_error_rate = max_error_rate
@@ -97,10 +101,10 @@ class Aligner:
                     c_diag, c_del, c_ins = d_cost + 1, cost[i] + 1, cost[i - 1] + 1
                     if c_diag <= c_del and c_diag <= c_ins:
                         c, o, s = c_diag, d_origin, d_score - 1
-                    elif c_del <= c_ins:
-                        c, o, s = c_del, origin[i], score[i] - 2
-                    else:
+                    elif (c_ins <= c_del) if self.indel_tie == TIE_INSERTION else (c_ins < c_del):
                         c, o, s = c_ins, origin[i - 1], score[i - 1] - 2
+                    else:
+                        c, o, s = c_del, origin[i], score[i] - 2
                 d_cost, d_score, d_origin = cost[i], score[i], origin[i]
                 cost[i], origin[i], score[i] = c, o, s
             while last >= 0 and cost[last] > k:
@@ -154,7 +158,9 @@ class SingleAdapter:
     remove_before = False
 
     def __init__(self, sequence: str, max_errors: float = 0.1, min_overlap: int = 3,
-                 select_rule: int = SELECT_LEFTMOST):
+                 select_rule: int = SELECT_LEFTMOST, indel_tie: int = TIE_INSERTION,
+                 case_rule: int = CASE_FOLD, shortcut: int = SHORTCUT_NONE):
+        self.indel_tie, self.case_rule, self.shortcut = indel_tie, case_rule, shortcut
         self.sequence = sequence.upper().replace("U", "T")
         if not self.sequence:
             raise ValueError("Adapter sequence is empty")
@@ -166,7 +172,12 @@ class SingleAdapter:
         self.aligner = self._aligner()
 
     def _aligner(self):
-        return Aligner(self.sequence, self.max_error_rate, self.where, self.min_overlap, self.select_rule)
+        return Aligner(self.sequence, self.max_error_rate, self.where, self.min_overlap, self.select_rule,
+                       self.indel_tie)
+
+    def _seen(self, sequence: str) -> str:
+        """The read as the aligner sees it: ``sequence.upper()`` (cutadapt ``match_to``)."""
+        return sequence.upper() if self.case_rule == CASE_FOLD else sequence
 
     def _wrap(self, alignment):
         if alignment is None:
@@ -174,7 +185,7 @@ class SingleAdapter:
         return Match(*alignment, adapter=self, remove_before=self.remove_before)
 
     def match_to(self, sequence: str):
-        return self._wrap(self.aligner.locate(sequence))
+        return self._wrap(self.aligner.locate(self._seen(sequence)))
 
 
 class BackAdapter(SingleAdapter):
@@ -183,24 +194,35 @@ class BackAdapter(SingleAdapter):
         super().__init__(sequence, max_errors, min_overlap, **kw)
 
     def match_to(self, sequence: str):
-        pos = sequence.find(self.sequence)  # exact occurrence first
-        if pos >= 0:
-            m = len(self.sequence)
-            return self._wrap((0, m, pos, pos + m, m, 0))
+        sequence = self._seen(sequence)
+        if self.shortcut == SHORTCUT_FIND:  # cutadapt <= 2.x: exact occurrence first (opt-in)
+            pos = sequence.find(self.sequence)
+            if pos >= 0:
+                m = len(self.sequence)
+                return self._wrap((0, m, pos, pos + m, m, 0))
         return self._wrap(self.aligner.locate(sequence))
+
+
+class FrontAdapter(SingleAdapter):
+    """Regular 5' adapter (``-g``); cutseq only uses the rightmost variant, the guide tables use this one."""
+    where = FRONT
+    remove_before = True
 
 
 class RightmostFrontAdapter(SingleAdapter):
     remove_before = True
 
     def _aligner(self):
-        return Aligner(self.sequence[::-1], self.max_error_rate, BACK, self.min_overlap, self.select_rule)
+        return Aligner(self.sequence[::-1], self.max_error_rate, BACK, self.min_overlap, self.select_rule,
+                       self.indel_tie)
 
     def match_to(self, sequence: str):
+        sequence = self._seen(sequence)
         m, n = len(self.sequence), len(sequence)
-        pos = sequence.rfind(self.sequence)
-        if pos >= 0:
-            return self._wrap((0, m, pos, pos + m, m, 0))
+        if self.shortcut == SHORTCUT_FIND:
+            pos = sequence.rfind(self.sequence)
+            if pos >= 0:
+                return self._wrap((0, m, pos, pos + m, m, 0))
         aln = self.aligner.locate(sequence[::-1])
         if aln is None:
             return None
@@ -222,6 +244,7 @@ class PrefixAdapter(SingleAdapter):
     remove_before = True
 
     def __init__(self, sequence, max_errors=0.1, **kw):
+        kw.pop("shortcut", None)
         super().__init__(sequence, max_errors, len(sequence), **kw)
 
 
@@ -229,6 +252,7 @@ class SuffixAdapter(SingleAdapter):
     where = SUFFIX
 
     def __init__(self, sequence, max_errors=0.1, **kw):
+        kw.pop("shortcut", None)
         super().__init__(sequence, max_errors, len(sequence), **kw)
 
 
@@ -380,23 +404,30 @@ class Settings:
     force_trim_min_length: int = 50
     force_anywhere: bool = False
     select_rule: int = SELECT_LEFTMOST
+    indel_tie: int = TIE_INSERTION
+    case_rule: int = CASE_FOLD
+    shortcut: int = SHORTCUT_NONE
+
+    def rules(self) -> dict:
+        return dict(select_rule=self.select_rule, indel_tie=self.indel_tie, case_rule=self.case_rule,
+                    shortcut=self.shortcut)
 
 
 class SinglePipeline:
     """pipeline_single restated: ``process(read)`` -> (route, Read)."""
 
     def __init__(self, bc, st: Settings, untrimmed_requested=False):
-        e, sel = 0.2, st.select_rule
+        e, rules = 0.2, st.rules()
         self.mods = [SuffixRemover(".1"), SuffixRemover("/1")]
-        self.mods.append(AdapterCutter(RightmostFrontAdapter(bc.p5.fw, e, 10, select_rule=sel)))
-        self.mods.append(AdapterCutter(BackAdapter(bc.p7.fw, e, 3, st.force_anywhere, select_rule=sel)))
+        self.mods.append(AdapterCutter(RightmostFrontAdapter(bc.p5.fw, e, 10, **rules)))
+        self.mods.append(AdapterCutter(BackAdapter(bc.p7.fw, e, 3, st.force_anywhere, **rules)))
         self.required = []
         if bc.inline5.len:
-            a = PrefixAdapter(bc.inline5.fw, e, select_rule=sel)
+            a = PrefixAdapter(bc.inline5.fw, e, **rules)
             self.required.append(a)
             self.mods.append(AdapterCutter(a))
         if bc.inline3.len:
-            a = SuffixAdapter(bc.inline3.fw, e, select_rule=sel)
+            a = SuffixAdapter(bc.inline3.fw, e, **rules)
             self.required.append(a)
             self.mods.append(AdapterCutter(a))
         if bc.umi5.len:
@@ -410,8 +441,8 @@ class SinglePipeline:
         if bc.mask3.len:
             self.mods.append(UnconditionalCutter(-bc.mask3.len))
         if st.trim_polyA:
-            fwd = lambda: AdapterCutter(NonInternalBackAdapter("A" * 100, 0.15, select_rule=sel))
-            rev = lambda: AdapterCutter(NonInternalFrontAdapter("T" * 100, 0.15, select_rule=sel))
+            fwd = lambda: AdapterCutter(NonInternalBackAdapter("A" * 100, 0.15, **rules))
+            rev = lambda: AdapterCutter(NonInternalFrontAdapter("T" * 100, 0.15, **rules))
             if st.trim_polyA_wo_direction:
                 self.mods += [fwd(), rev()]
             elif bc.strand == "+":
@@ -452,23 +483,23 @@ class PairedPipeline:
     """pipeline_paired restated: ``process(r1, r2)`` -> (route, Read, Read)."""
 
     def __init__(self, bc, st: Settings, untrimmed_requested=False):
-        e, sel, f = 0.2, st.select_rule, st.force_trim_min_length
+        e, rules, f = 0.2, st.rules(), st.force_trim_min_length
 
         def cond(n):
             return ConditionalCutter(n, f) if st.conditional_cutter else UnconditionalCutter(n)
 
         mods = [(SuffixRemover(".1"), SuffixRemover(".2")), (SuffixRemover("/1"), SuffixRemover("/2"))]
-        mods.append((AdapterCutter(RightmostFrontAdapter(bc.p5.fw, e, 10, select_rule=sel)),
-                     AdapterCutter(RightmostFrontAdapter(bc.p7.rc, e, 10, select_rule=sel))))
-        mods.append((AdapterCutter(BackAdapter(bc.p7.fw, e, 3, st.force_anywhere, select_rule=sel)),
-                     AdapterCutter(BackAdapter(bc.p5.rc, e, 3, st.force_anywhere, select_rule=sel))))
+        mods.append((AdapterCutter(RightmostFrontAdapter(bc.p5.fw, e, 10, **rules)),
+                     AdapterCutter(RightmostFrontAdapter(bc.p7.rc, e, 10, **rules))))
+        mods.append((AdapterCutter(BackAdapter(bc.p7.fw, e, 3, st.force_anywhere, **rules)),
+                     AdapterCutter(BackAdapter(bc.p5.rc, e, 3, st.force_anywhere, **rules))))
         self.req1, self.req2 = [], []
         if bc.inline5.len:
-            a = PrefixAdapter(bc.inline5.fw, e, select_rule=sel)
+            a = PrefixAdapter(bc.inline5.fw, e, **rules)
             self.req1.append(a)
             mods.append((AdapterCutter(a), UnconditionalCutter(-bc.inline5.len)))
         if bc.inline3.len:
-            a = PrefixAdapter(bc.inline3.rc, e, select_rule=sel)
+            a = PrefixAdapter(bc.inline3.rc, e, **rules)
             self.req2.append(a)
             mods.append((UnconditionalCutter(-bc.inline3.len), AdapterCutter(a)))
         if bc.umi5.len:
@@ -482,8 +513,8 @@ class PairedPipeline:
         if bc.mask3.len:
             mods.append((cond(-bc.mask3.len), UnconditionalCutter(bc.mask3.len)))
         if st.trim_polyA:
-            pa = lambda: AdapterCutter(NonInternalBackAdapter("A" * 100, 0.15, select_rule=sel))
-            pt = lambda: AdapterCutter(NonInternalFrontAdapter("T" * 100, 0.15, select_rule=sel))
+            pa = lambda: AdapterCutter(NonInternalBackAdapter("A" * 100, 0.15, **rules))
+            pt = lambda: AdapterCutter(NonInternalFrontAdapter("T" * 100, 0.15, **rules))
             if st.trim_polyA_wo_direction:
                 mods += [(pa(), pt()), (pt(), pa())]
             elif bc.strand == "+":

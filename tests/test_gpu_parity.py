@@ -68,11 +68,13 @@ def adversarial_reads(rng: random.Random, ref: str, count: int, alpha: str, max_
     return reads
 
 
-def one_adapter_plan(seq, rate, min_overlap, where, remove, rightmost=False, shortcut=0, rule=0, use_filter=True):
+def one_adapter_plan(seq, rate, min_overlap, where, remove, rightmost=False, shortcut=0, rule=0, use_filter=True,
+                     tie=abi.CS_TIE_INSERTION, case=abi.CS_CASE_FOLD):
     op = planmod.AdapterOp("test", seq, rate, min_overlap, where, remove, rightmost=rightmost, shortcut=shortcut,
                            match_flag=abi.CS_F_ADAPTER3)
     return planmod.TrimPlan(r1=planmod.MateChain([op]), r2=None, has_umi=False, min_length=0,
-                            untrimmed_filter=False, select_rule=rule, use_filter=use_filter)
+                            untrimmed_filter=False, select_rule=rule, use_filter=use_filter, indel_tie=tie,
+                            case_rule=case)
 
 
 @pytest.mark.parametrize("use_filter", [True, False])
@@ -90,9 +92,12 @@ def test_single_adapter_all_flag_sets(where, rule, use_filter):
         mo = rng.randint(1, m)
         remove = rng.choice([abi.CS_REMOVE_BEFORE, abi.CS_REMOVE_AFTER])
         rightmost = rng.random() < 0.3
-        shortcut = abi.CS_SHORTCUT_FIND if rng.random() < 0.5 else abi.CS_SHORTCUT_NONE
-        tp = one_adapter_plan(ref, rate, mo, WHERE[where], remove, rightmost, shortcut, rule, use_filter)
+        shortcut = abi.CS_SHORTCUT_FIND if rng.random() < 0.3 else abi.CS_SHORTCUT_NONE
+        tie = rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION])
+        case = abi.CS_CASE_SENSITIVE if rng.random() < 0.25 else abi.CS_CASE_FOLD
+        tp = one_adapter_plan(ref, rate, mo, WHERE[where], remove, rightmost, shortcut, rule, use_filter, tie, case)
         batch = util.batch_from_reads(adversarial_reads(rng, ref, 700, alpha))
+        util.soft_mask(batch, 0.15, seed=trial)
         run_both(tp, batch, threads=4)
 
 
@@ -173,6 +178,7 @@ def test_chain_presets(name, flags, paired, rule):
             continue
         cut = rng.random(batch.n) < 0.25
         lens[cut] = rng.integers(0, 150, size=int(cut.sum())).astype(np.uint16)
+    util.soft_mask(batch, 0.2)
     tp = util.compile_plan(scheme, st, paired)
     run_both(tp, batch)
 
@@ -381,6 +387,9 @@ def test_fuzz_odd_alphabets_qualities_and_lengths(seed):
         st.min_quality = rng.choice([0, 2, 20, 30, 41, 93])
         st.force_trim_min_length = rng.choice([0, 50, 120, 10000])
         st.select_rule = rng.choice([0, 1])
+        st.indel_tie = rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION])
+        st.case_rule = abi.CS_CASE_SENSITIVE if rng.random() < 0.25 else abi.CS_CASE_FOLD
+        st.shortcut = abi.CS_SHORTCUT_FIND if rng.random() < 0.25 else abi.CS_SHORTCUT_NONE
         paired = rng.random() < 0.7
         pieces = [bc.p5.fw, bc.p7.fw, bc.p5.rc, bc.p7.rc, "A" * 30, "T" * 30]
         reads1, reads2 = [], []
@@ -423,10 +432,40 @@ def test_full_hit_inside_plus_partial_hit_at_the_end(rule, use_filter):
         tail = util.mutate(rng, ad[: rng.randint(3, 19)], rng.choice([0, 0, 1, 1, 2]))
         s = (head + hit + gap + tail)[:200]
         reads.append((s, "I" * len(s)))
-    for where, mo, shortcut in (("BACK", 3, 1), ("ANYWHERE", 3, 1), ("BACK", 10, 0)):
-        tp = one_adapter_plan(ad, 0.2, mo, WHERE[where], abi.CS_REMOVE_AFTER, False, shortcut, rule, use_filter)
+    for where, mo, shortcut, tie in (("BACK", 3, 1, 0), ("ANYWHERE", 3, 1, 1), ("BACK", 10, 0, 1), ("BACK", 3, 0, 0),
+                                     ("ANYWHERE", 3, 0, 0)):
+        tp = one_adapter_plan(ad, 0.2, mo, WHERE[where], abi.CS_REMOVE_AFTER, False, shortcut, rule, use_filter, tie)
         run_both(tp, util.batch_from_reads(reads), threads=8)
     # the same through the reversed aligner (RightmostFrontAdapter)
     rev = [(s[::-1], q) for s, q in reads]
-    tp = one_adapter_plan(ad[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, True, 1, rule, use_filter)
-    run_both(tp, util.batch_from_reads(rev), threads=8)
+    for shortcut in (1, 0):
+        tp = one_adapter_plan(ad[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, True, shortcut, rule, use_filter)
+        run_both(tp, util.batch_from_reads(rev), threads=8)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_inexact_occurrence_in_front_of_an_exact_one(rule):
+    """No short cut (the default): an exact copy does not win by itself.  A damaged copy at every distance
+    in front of it -- inside the m/2 overlap window (the exact one replaces it), just outside, far away
+    (leftmost rule: the damaged one stays; score rule: the exact one wins) -- and the filter's own
+    decision 'exact hit right behind its own run' against the full DP."""
+    rng = random.Random(97 + rule)
+    ad = "AGATCGGAAGAGCACACGTC"
+    reads = []
+    for _ in range(3000):
+        head = util.random_dna(rng, rng.randint(0, 40))
+        bad = util.mutate(rng, ad, rng.randint(1, 4))
+        gap = util.random_dna(rng, rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 20, 30]))
+        if rng.random() < 0.3:
+            bad, gap = "", ""
+        s = (head + bad + gap + ad + util.random_dna(rng, rng.randint(0, 12)))[:220]
+        reads.append((s, "I" * len(s)))
+    batch = util.batch_from_reads(reads)
+    util.soft_mask(batch, 0.1)
+    for use_filter in (True, False):
+        for tie in (abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION):
+            tp = one_adapter_plan(ad, 0.2, 3, WHERE["BACK"], abi.CS_REMOVE_AFTER, False, 0, rule, use_filter, tie)
+            run_both(tp, batch, threads=8)
+    rev = util.batch_from_reads([(s[::-1], q) for s, q in reads])
+    tp = one_adapter_plan(ad[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, True, 0, rule, True)
+    run_both(tp, rev, threads=8)

@@ -104,9 +104,46 @@ def test_select_rules_differ_on_worse_then_better_occurrence():
     score = oracle.locate(ad, read, 0.2, abi.CS_WHERE_BACK, 3, abi.CS_SELECT_SCORE)
     assert left[2] == 8 and left[5] == 1
     assert score[2] == 8 + 16 + 20 and score[5] == 0
-    # ...but BackAdapter.match_to tries str.find first, so the adapter-level answer is the exact copy
+    # the adapter-level answer is the aligner's (cutadapt >= 3: match_to has no str.find in front of it) ...
     m = pyref.BackAdapter(ad, 0.2, 3).match_to(read)
+    assert (m.rstart, m.errors) == (8, 1)
+    # ... unless the cutadapt <= 2.x short cut is switched on: then the exact copy behind it wins
+    m = pyref.BackAdapter(ad, 0.2, 3, shortcut=pyref.SHORTCUT_FIND).match_to(read)
     assert (m.rstart, m.errors) == (44, 0)
+    # the same through the op table / C oracle
+    for sc, want in ((abi.CS_SHORTCUT_NONE, 8), (abi.CS_SHORTCUT_FIND, 44)):
+        tp = _one_read_plan([planmod.back(ad, 0.2, 3, flag=abi.CS_F_ADAPTER3, shortcut=sc)])
+        r, _ = _run_single(tp, read)
+        assert int(r["stop"]) == want
+
+
+def test_exact_hit_right_behind_an_inexact_run_replaces_it():
+    """An exact copy is preceded by its own run of inexact candidates (the same occurrence seen k
+    columns early): they overlap, the exact column scores higher and Aligner.locate stops there."""
+    ad = "AGATCGGAAGAGCACACGTC"
+    ins = "TTGACCTGAACCTTGGAACCTTGACCTGAA"
+    for rule in (0, 1):
+        assert oracle.locate(ad, ins + ad + "TTGG", 0.2, abi.CS_WHERE_BACK, 3, rule)[2:6] == (30, 50, 20, 0)
+
+
+def test_indel_tie_rule_changes_the_origin():
+    """cost_insertion == cost_deletion < cost_diag: the two orders take origin/score from different
+    cells.  CS_TIE_INSERTION is SURVEY.md appendix B.2's order; both are restated, C == Python."""
+    rng = random.Random(77)
+    differ = 0
+    for _ in range(3000):
+        ref = util.random_dna(rng, rng.randint(6, 20))
+        query = util.random_dna(rng, rng.randint(0, 10)) + util.mutate(rng, ref, rng.randint(1, 4)) + \
+            util.random_dna(rng, rng.randint(0, 10))
+        rate = rng.choice([0.2, 0.3])
+        res = []
+        for tie in (abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION):
+            c = oracle.locate(ref, query, rate, abi.CS_WHERE_BACK, 3, 0, tie)
+            p = pyref.Aligner(ref, rate, pyref.BACK, 3, 0, tie).locate(query)
+            assert c == p
+            res.append(c)
+        differ += res[0] != res[1]
+    assert differ > 0
 
 
 def test_rightmost_front_adapter():
@@ -114,9 +151,12 @@ def test_rightmost_front_adapter():
     read = "TT" + ad + "GGAGG" + ad + "CCATTGGA"
     m = pyref.RightmostFrontAdapter(ad, 0.2, 10).match_to(read)
     assert m.rstop == 2 + 20 + 5 + 20
-    # one mismatch in the right copy: the exact left copy wins through rfind
+    # one mismatch in the right copy: it is still the rightmost occurrence (the aligner walks the reversed
+    # read and keeps its first hit); only the cutadapt <= 2.x rfind short cut prefers the exact left copy
     read2 = "TT" + ad + "GGAGG" + ad[:5] + "T" + ad[6:] + "CCATTGGA"
     m2 = pyref.RightmostFrontAdapter(ad, 0.2, 10).match_to(read2)
+    assert m2.rstop == 47 and m2.errors == 1
+    m2 = pyref.RightmostFrontAdapter(ad, 0.2, 10, shortcut=pyref.SHORTCUT_FIND).match_to(read2)
     assert m2.rstop == 22
     # no exact copy at all: aligner on the reversed strings finds the rightmost one
     bad = ad[:5] + "T" + ad[6:]
@@ -299,6 +339,10 @@ CHAIN_CASES = [
      {"ensure_inline_barcode": True, "trim_polyA": True}, True),
     ("ACACGACGCTCTTCCGATCT(ATCACG)NNNNNNNNXX<XXXNNNN(CGATGT)AGATCGGAAGAGCACACGTC",
      {"ensure_inline_barcode": True}, False),
+    # the recalled cutadapt rules, each switched to its non-default setting (include/cutseq_hip.h)
+    ("TAKARAV3", {"trim_polyA": True, "shortcut": abi.CS_SHORTCUT_FIND}, True),
+    ("TAKARAV3", {"trim_polyA": True, "indel_tie": abi.CS_TIE_DELETION}, True),
+    ("SACSEQV3", {"case_rule": abi.CS_CASE_SENSITIVE, "indel_tie": abi.CS_TIE_DELETION}, False),
 ]
 
 
@@ -319,6 +363,7 @@ def test_chain_matches_string_pipeline(name, flags, paired, rule):
             continue
         cut = rng.random(batch.n) < 0.25
         lens[cut] = rng.integers(0, 150, size=int(cut.sum())).astype(np.uint16)
+    util.soft_mask(batch, 0.2)
     names1 = [f"SIM:{i} 1:N:0:X".encode() for i in range(batch.n)]
     names2 = [f"SIM:{i} 2:N:0:X".encode() for i in range(batch.n)]
     names1[5], names2[5] = b"plain/1", b"plain/2"

@@ -78,7 +78,7 @@ def to_pyref_settings(st: planmod.CutadaptConfig) -> pyref.Settings:
         trim_polyA_wo_direction=st.trim_polyA_wo_direction, conditional_cutter=st.conditional_cutter,
         min_length=st.min_length, min_quality=st.min_quality, auto_rc=st.auto_rc,
         force_trim_min_length=st.force_trim_min_length, force_anywhere=st.force_anywhere,
-        select_rule=st.select_rule,
+        select_rule=st.select_rule, indel_tie=st.indel_tie, case_rule=st.case_rule, shortcut=st.shortcut,
     )
 
 
@@ -151,3 +151,20 @@ def mutate(rng: random.Random, s: str, n_edits: int, alphabet="ACGT") -> str:
         elif s:
             del s[rng.randrange(len(s))]
     return "".join(s)
+
+
+def soft_mask(batch: SynthBatch, fraction: float = 0.2, seed: int = 9) -> None:
+    """Lower-case a random stretch of `fraction` of the reads in place (soft-masked bases): the
+    aligner sees them through sequence.upper(), the output keeps them."""
+    rng = np.random.default_rng(seed)
+    for seq in (batch.seq1, batch.seq2):
+        if seq is None:
+            continue
+        n, stride = seq.shape
+        rows = np.nonzero(rng.random(n) < fraction)[0]
+        for r in rows:
+            lo = int(rng.integers(0, stride))
+            hi = int(rng.integers(lo, stride + 1))
+            seg = seq[r, lo:hi]
+            letters = (seg >= ord("A")) & (seg <= ord("Z"))
+            seg[letters] |= 0x20
