@@ -32,7 +32,11 @@ int fail(int code, const char *fmt, ...) {
                                       __FILE__, __LINE__);                                         \
   } while (0)
 
-constexpr size_t kTileCounterBytes = 2 * csdev::kTileCounters * csdev::kTileCounterStride * sizeof(uint32_t);
+// tile hand-out counters of the scan kernel [2][kTileCounters], then the queue counters (records written
+// per mate, batches claimed per mate), every counter on a 128-byte line of its own
+constexpr size_t kTileCounterDwords = 2 * csdev::kTileCounters * csdev::kTileCounterStride;
+constexpr size_t kTileCounterBytes = (kTileCounterDwords + 4 * csdev::kTileCounterStride) * sizeof(uint32_t);
+constexpr size_t kDeferRecordBytes = 32;
 constexpr uint32_t kTileRows = 64;  // one wave per block: no block-level synchronisation at all
 constexpr uint32_t kLdsBudget = 160 * 1024;
 
@@ -88,10 +92,16 @@ struct cs_engine {
   bool wide = false;  // some adapter needs 64-bit bit-vectors
   int n_cus = 256;
   uint32_t n_table_ops = 1;
-  uint32_t col_dwords = 0;   // per-wave DP scratch the plan needs
-  uint32_t waves_per_simd = 4;  // from the kernel's register count
+  uint32_t col_dwords = 0;   // per-wave DP scratch the plan needs (resolve kernel)
+  uint32_t waves_per_simd[2] = {4, 4};  // scan / resolve kernel, from their register counts
   std::vector<Slot> slots;
-  uint32_t max_dynamic_lds = 0;
+  uint32_t max_dynamic_lds[2] = {0, 0};
+  void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
+  uint32_t defer_capacity = 0;            // records per mate
+  // tuning knobs, read once from the environment when the engine is created
+  uint32_t knob_col_bytes = 0, knob_grid_x = 0;
+  bool knob_units = false;
+  uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 75;
 };
 
 namespace {
@@ -172,52 +182,55 @@ struct Geometry {
   uint32_t tile_rows, lds_stride_dw, col_dwords, lds_bytes;
 };
 
-const void *kernel_for(const cs_engine *eng) {
+template <int MODE>
+const void *kernel_of(const cs_engine *eng) {
   if (eng->coded)
-    return eng->wide ? reinterpret_cast<const void *>(csdev::trim_kernel<true, true>)
-                     : reinterpret_cast<const void *>(csdev::trim_kernel<true, false>);
-  return eng->wide ? reinterpret_cast<const void *>(csdev::trim_kernel<false, true>)
-                   : reinterpret_cast<const void *>(csdev::trim_kernel<false, false>);
+    return eng->wide ? reinterpret_cast<const void *>(csdev::trim_kernel<true, true, MODE>)
+                     : reinterpret_cast<const void *>(csdev::trim_kernel<true, false, MODE>);
+  return eng->wide ? reinterpret_cast<const void *>(csdev::trim_kernel<false, true, MODE>)
+                   : reinterpret_cast<const void *>(csdev::trim_kernel<false, false, MODE>);
+}
+const void *kernel_for(const cs_engine *eng, int mode) {
+  return mode == csdev::MODE_SCAN ? kernel_of<csdev::MODE_SCAN>(eng) : kernel_of<csdev::MODE_RESOLVE>(eng);
 }
 
-int geometry_for(const cs_engine *eng, uint32_t stride, Geometry &g) {
+int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   if (stride == 0 || stride % 4 || stride > CS_MAX_STRIDE)
     return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);
   // coded plans keep 4 bits per base (8 per dword), raw plans the ASCII bytes; odd dword
   // stride: conflict-free column walks
   g.lds_stride_dw = (eng->coded ? (stride + 7) / 8 : stride / 4) | 1u;
-  g.col_dwords = eng->col_dwords;
-  if (const char *env = getenv("CUTSEQ_COL_BYTES")) {  // tuning knob: LDS bytes of DP scratch per wave
-    const long v = atol(env);
-    if (v >= 1024 && v <= 32768 && (uint32_t)v / 4 > g.col_dwords) g.col_dwords = (uint32_t)v / 4;
+  // one wave per block: the kernel keeps per-block state (private mask table) on that basis.  Only the
+  // resolve kernel runs the DP: scratch columns and the survivor queue are its alone.
+  g.tile_rows = kTileRows;
+  g.col_dwords = 0;
+  uint32_t words = kTileRows * g.lds_stride_dw + eng->n_table_ops * (csdev::kEqTableBytes / 4) + csdev::kStatWords +
+                   96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
+  if (mode == csdev::MODE_RESOLVE) {
+    g.col_dwords = eng->col_dwords;
+    if (eng->knob_col_bytes / 4 > g.col_dwords) g.col_dwords = eng->knob_col_bytes / 4;
+    words += g.col_dwords + 64 * csdev::kWaveItemDwords;
   }
-  uint32_t rows = kTileRows;  // one wave per block: the kernel keeps per-block state (private mask table) on that basis
-  for (;;) {
-    const uint32_t waves = rows / 64;
-    const uint32_t words = rows * g.lds_stride_dw + waves * (g.col_dwords + 64 * csdev::kWaveItemDwords) +
-                           eng->n_table_ops * (csdev::kEqTableBytes / 4) + csdev::kStatWords +
-                           96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
-    g.lds_bytes = words * 4;
-    if (g.lds_bytes <= kLdsBudget || rows == 64) break;
-    rows -= 64;
-  }
+  g.lds_bytes = words * 4;
   if (g.lds_bytes > kLdsBudget) return fail(CS_ERR_ARG, "stride %u does not fit the LDS tile", stride);
-  g.tile_rows = rows;
   return CS_OK;
 }
 
 int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
            uint32_t stride, bool time_it) {
-  Geometry g;
-  int rc = geometry_for(eng, stride, g);
-  if (rc) return rc;
+  Geometry g[2];
+  for (int mode = 0; mode < 2; ++mode) {
+    int rc = geometry_for(eng, stride, mode, g[mode]);
+    if (rc) return rc;
+  }
   if (n_reads == 0) return CS_OK;
   if ((r2 != nullptr) != eng->paired) return fail(CS_ERR_ARG, "plan is %s-end", eng->paired ? "paired" : "single");
   csdev::KArgs a;
   memset(&a, 0, sizeof a);
   const cs_reads *rr[2] = {r1, r2};
-  for (int m = 0; m < (r2 ? 2 : 1); ++m) {
-    if (!rr[m]->seq || !rr[m]->qual || !rr[m]->len || !rr[m]->out) return fail(CS_ERR_ARG, "null array in mate %d", m + 1);
+  const uint32_t mates = r2 ? 2 : 1;
+  for (uint32_t m = 0; m < mates; ++m) {
+    if (!rr[m]->seq || !rr[m]->qual || !rr[m]->len || !rr[m]->out) return fail(CS_ERR_ARG, "null array in mate %u", m + 1);
     if (((uintptr_t)rr[m]->seq | (uintptr_t)rr[m]->qual) & 3) return fail(CS_ERR_ARG, "seq/qual must be 4-byte aligned");
     a.mate[m].seq = reinterpret_cast<const uint32_t *>(rr[m]->seq);
     a.mate[m].qual = rr[m]->qual;
@@ -225,56 +238,71 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     a.mate[m].out = rr[m]->out;
     a.mate[m].cap2 = rr[m]->cap2;
   }
+  // queue of deferred reads: a read is deferred at most once by the scan kernel, so n_reads records per
+  // mate always suffice (32 bytes each; typically a few per cent are used)
+  if (n_reads > eng->defer_capacity) {
+    HIP_TRY(hipStreamSynchronize(stream));  // an earlier launch may still be reading the old queue
+    for (int m = 0; m < 2; ++m) {
+      if (eng->d_defer[m]) (void)hipFree(eng->d_defer[m]);
+      eng->d_defer[m] = nullptr;
+    }
+    eng->defer_capacity = 0;
+    const uint32_t cap = n_reads + n_reads / 8 + 1024;
+    for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) HIP_TRY(hipMalloc(&eng->d_defer[m], (size_t)cap * kDeferRecordBytes));
+    eng->defer_capacity = cap;
+  }
+  a.defer[0] = reinterpret_cast<uint4 *>(eng->d_defer[0]);
+  a.defer[1] = reinterpret_cast<uint4 *>(eng->d_defer[1]);
+  a.defer_count = eng->d_tile_counter + kTileCounterDwords;
   a.stats = eng->d_stats;
   a.n_reads = n_reads;
   a.stride_dw = stride / 4;
-  a.lds_stride_dw = g.lds_stride_dw;
-  a.col_dwords = g.col_dwords;
   a.plan_slot = (uint32_t)eng->plan_slot;
   a.tile_counter = eng->d_tile_counter;
   a.n_table_ops = eng->n_table_ops;
-  if (g.lds_bytes > eng->max_dynamic_lds) {
-    HIP_TRY(hipFuncSetAttribute(kernel_for(eng), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-    eng->max_dynamic_lds = g.lds_bytes;
+  for (int mode = 0; mode < 2; ++mode)
+    if (g[mode].lds_bytes > eng->max_dynamic_lds[mode]) {
+      HIP_TRY(hipFuncSetAttribute(kernel_for(eng, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g[mode].lds_bytes));
+      eng->max_dynamic_lds[mode] = g[mode].lds_bytes;
+    }
+  // persistent blocks: as many as stay resident (LDS- or register-limited), each loops over its tiles
+  const uint32_t n_tiles = (n_reads + kTileRows - 1) / kTileRows;
+  uint32_t gx[2];
+  for (int mode = 0; mode < 2; ++mode) {
+    uint32_t per_cu = kLdsBudget / g[mode].lds_bytes;
+    const uint32_t wave_cap = 4 * eng->waves_per_simd[mode];
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
+    // scan kernel: 2x the resident set, late blocks even out the tail; resolve kernel: the resident set
+    uint32_t resident = (uint32_t)eng->n_cus * per_cu * (mode == csdev::MODE_SCAN ? 2u : 1u);
+    gx[mode] = resident / mates;
+    if (mode == csdev::MODE_SCAN && eng->knob_grid_x) gx[mode] = eng->knob_grid_x;
+    if (gx[mode] < 1) gx[mode] = 1;
+    if (gx[mode] > n_tiles) gx[mode] = n_tiles;
   }
-  // persistent blocks: as many as stay resident (LDS-limited), each loops over its tiles
-  const uint32_t n_tiles = (n_reads + g.tile_rows - 1) / g.tile_rows;
-  uint32_t per_cu = kLdsBudget / g.lds_bytes;
-  const uint32_t wave_cap = (4 * eng->waves_per_simd) / (g.tile_rows / 64);
-  if (per_cu > wave_cap) per_cu = wave_cap;
-  if (per_cu < 1) per_cu = 1;
-  uint32_t resident = (uint32_t)eng->n_cus * per_cu * 2;  // 2x: late blocks even out the tail
-  const uint32_t mates = r2 ? 2 : 1;
-  uint32_t gx = resident / mates;
-  if (const char *env = getenv("CUTSEQ_GRID_X")) {
-    const long v = atol(env);
-    if (v > 0) gx = (uint32_t)v;
-  }
-  if (gx < 1) gx = 1;
-  if (gx > n_tiles) gx = n_tiles;
   // tile hand-out (see the kernel): big units, about a quarter of a block's share (at most 8 tiles), for
   // the first 3/4 of the batch, single tiles for the rest.
-  a.static_units = gx / 2 > 0 ? gx / 2 : 1;  // the half of the grid that is resident from the start
+  a.static_units = gx[0] / 2 > 0 ? gx[0] / 2 : 1;  // the half of the grid that is resident from the start
   const uint32_t share = n_tiles / a.static_units;
   a.big_shift = share >= 32 ? 3 : share >= 16 ? 2 : 1;
   a.small_shift = 0;
   uint32_t big_pct = 75;
-  if (const char *env = getenv("CUTSEQ_UNITS")) {  // tuning knob: "big_shift,small_shift,big_pct"
-    unsigned bs, ss, pc;
-    if (sscanf(env, "%u,%u,%u", &bs, &ss, &pc) == 3 && bs <= 6 && ss <= bs && pc <= 100) {
-      a.big_shift = bs;
-      a.small_shift = ss;
-      big_pct = pc;
-    }
+  if (eng->knob_units) {
+    a.big_shift = eng->knob_big_shift;
+    a.small_shift = eng->knob_small_shift;
+    big_pct = eng->knob_big_pct;
   }
   a.big_tiles = (uint32_t)((uint64_t)n_tiles * big_pct / 100) & ~((1u << a.big_shift) - 1u);
-  dim3 grid(gx, mates, 1);
-  dim3 block(g.tile_rows, 1, 1);
   HIP_TRY(hipMemsetAsync(eng->d_tile_counter, 0, kTileCounterBytes, stream));
   if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
-  void *kargs[] = {&a};
-  HIP_TRY(hipLaunchKernel(kernel_for(eng), grid, block, kargs, g.lds_bytes, stream));
-  HIP_TRY(hipGetLastError());
+  for (int mode = 0; mode < 2; ++mode) {
+    a.lds_stride_dw = g[mode].lds_stride_dw;
+    a.col_dwords = g[mode].col_dwords;
+    void *kargs[] = {&a};
+    HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
+                            g[mode].lds_bytes, stream));
+    HIP_TRY(hipGetLastError());
+  }
   if (time_it) {
     HIP_TRY(hipEventRecord(eng->ev_stop, stream));
     eng->timed = true;
@@ -359,6 +387,8 @@ void cs_engine_destroy(cs_engine *eng) {
   if (eng->plan_slot >= 0) release_plan_slot(eng->device, eng->plan_slot);
   if (eng->d_stats) (void)hipFree(eng->d_stats);
   if (eng->d_tile_counter) (void)hipFree(eng->d_tile_counter);
+  for (int m = 0; m < 2; ++m)
+    if (eng->d_defer[m]) (void)hipFree(eng->d_defer[m]);
   if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
   if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
@@ -443,12 +473,30 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     ENG_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   }
 #undef ENG_TRY
-  {
+  for (int mode = 0; mode < 2; ++mode) {
     hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, kernel_for(eng)) == hipSuccess && fa.numRegs > 0) {
+    if (hipFuncGetAttributes(&fa, kernel_for(eng, mode)) == hipSuccess && fa.numRegs > 0) {
       const uint32_t alloc = ((uint32_t)fa.numRegs + 7u) / 8u * 8u;
       uint32_t w = 512u / alloc;
-      eng->waves_per_simd = w < 1 ? 1 : (w > 8 ? 8 : w);
+      eng->waves_per_simd[mode] = w < 1 ? 1 : (w > 8 ? 8 : w);
+    }
+  }
+  // tuning knobs (diagnostic): read here, once, not on the launch path
+  if (const char *env = getenv("CUTSEQ_COL_BYTES")) {  // LDS bytes of DP scratch per wave
+    const long v = atol(env);
+    if (v >= 1024 && v <= 32768) eng->knob_col_bytes = (uint32_t)v;
+  }
+  if (const char *env = getenv("CUTSEQ_GRID_X")) {
+    const long v = atol(env);
+    if (v > 0) eng->knob_grid_x = (uint32_t)v;
+  }
+  if (const char *env = getenv("CUTSEQ_UNITS")) {  // "big_shift,small_shift,big_pct"
+    unsigned bs, ss, pc;
+    if (sscanf(env, "%u,%u,%u", &bs, &ss, &pc) == 3 && bs <= 6 && ss <= bs && pc <= 100) {
+      eng->knob_units = true;
+      eng->knob_big_shift = bs;
+      eng->knob_small_shift = ss;
+      eng->knob_big_pct = pc;
     }
   }
   *out = eng;
