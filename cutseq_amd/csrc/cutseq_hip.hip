@@ -204,7 +204,8 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   // resolve kernel runs the DP: scratch columns and the survivor queue are its alone.
   g.tile_rows = kTileRows;
   g.col_dwords = 0;
-  uint32_t words = kTileRows * g.lds_stride_dw + eng->n_table_ops * (csdev::kEqTableBytes / 4) + csdev::kStatWords +
+  uint32_t words = kTileRows * g.lds_stride_dw + eng->n_table_ops * (csdev::kEqTableBytes / 4 + csdev::kFnibDwords) +
+                   csdev::kStatWords +
                    96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
   if (mode == csdev::MODE_RESOLVE) {
     g.col_dwords = eng->col_dwords;
