@@ -13,7 +13,8 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-LIB = ROOT / "tools" / "ab" / "libcutseq_hip_timers.so"
+WHICH = os.environ.get("CS_TIMERS_KERNEL", "1")  # 1 = scan kernel, 2 = resolve kernel
+LIB = ROOT / "tools" / "ab" / f"libcutseq_hip_timers{WHICH}.so"
 PHASES = ["stage tile (loads + recode + barrier)", "filter: column scan", "filter: end rows / short cuts / verdict",
           "exact DP: queue, pass set-up, end rows, result", "poly-A/T closed form", "quality trim (+ fixed cuts)",
           "results, statistics, barrier", "exact DP: strip step loop"]
@@ -21,9 +22,11 @@ PHASES = ["stage tile (loads + recode + barrier)", "filter: column scan", "filte
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     LIB.parent.mkdir(exist_ok=True)
     src = ROOT / "cutseq_amd" / "csrc" / "cutseq_hip.hip"
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DCS_PHASE_TIMERS",
-                    "-o", str(LIB), str(src)], check=True, cwd=str(src.parent))
-    print(LIB)
+    for which in ("1", "2"):
+        lib = ROOT / "tools" / "ab" / f"libcutseq_hip_timers{which}.so"
+        subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+                        f"-DCS_PHASE_TIMERS={which}", "-o", str(lib), str(src)], check=True, cwd=str(src.parent))
+        print(lib)
     sys.exit(0)
 
 os.environ["CUTSEQ_HIP_LIB"] = str(LIB)
@@ -56,7 +59,7 @@ eng.trim_device(r1, r2, n, batch.stride)
 torch.cuda.synchronize()
 ms = eng.last_kernel_ms()
 stats = eng.stats()
-print(f"{n} pairs, kernel {ms:.3f} ms (instrumented build)")
+print(f"{n} pairs, both kernels {ms:.3f} ms (instrumented build), reporting: {'scan' if WHICH == '1' else 'resolve'} kernel")
 for mate, s in enumerate(stats):
     t = np.array([int(s.op_matched[16 + i]) for i in range(8)], dtype=np.float64) * 64
     tot = t.sum()
