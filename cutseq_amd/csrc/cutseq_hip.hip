@@ -99,7 +99,7 @@ struct cs_engine {
   void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
   uint32_t defer_capacity = 0;            // records per mate
   // tuning knobs, read once from the environment when the engine is created
-  uint32_t knob_col_bytes = 0, knob_grid_x = 0;
+  uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 0;
   bool knob_units = false;
   uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 75;
 };
@@ -261,6 +261,7 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
   a.plan_slot = (uint32_t)eng->plan_slot;
   a.tile_counter = eng->d_tile_counter;
   a.n_table_ops = eng->n_table_ops;
+  a.batch_knob = eng->knob_batch;
   for (int mode = 0; mode < 2; ++mode)
     if (g[mode].lds_bytes > eng->max_dynamic_lds[mode]) {
       HIP_TRY(hipFuncSetAttribute(kernel_for(eng, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g[mode].lds_bytes));
@@ -487,6 +488,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     const long v = atol(env);
     if (v >= 1024 && v <= 32768) eng->knob_col_bytes = (uint32_t)v;
   }
+  if (const char *env = getenv("CUTSEQ_BATCH_KNOB")) eng->knob_batch = (uint32_t)atol(env);
   if (const char *env = getenv("CUTSEQ_GRID_X")) {
     const long v = atol(env);
     if (v > 0) eng->knob_grid_x = (uint32_t)v;
