@@ -1,0 +1,249 @@
+"""gzip codec of the CLI (tier E; counterpart of xopen as cutadapt drives it for the reference,
+cutseq/run.py:434-441, 751-758).
+
+Output: one gzip member per block, level 1 (cutadapt's default), compressed in the caller's
+thread pool -- libdeflate when ``libdeflate.so.0`` can be loaded, zlib otherwise.
+Input: a stream of decompressed blocks.
+  * BGZF (block boundaries in the headers): blocks inflate in parallel in the pool;
+  * any other gzip file: member by member with libdeflate (one call per member, 2-3x zlib's rate;
+    multi-member files -- this tool's own output -- never hold more than one member in memory);
+  * a member too large for that (> ``_MEMBER_CAP`` decompressed), or no libdeflate: zlib streaming.
+The decompressed byte stream is what parity is defined on; the compressed bytes depend on the codec.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import mmap
+import struct
+import threading
+import zlib
+from typing import Iterator, Optional
+
+_MEMBER_CAP = 1 << 30   # largest decompressed member taken in one libdeflate call
+_STREAM_BLOCK = 8 << 20
+
+_lib = None
+_lib_tried = False
+_tls = threading.local()
+
+
+def libdeflate():
+    """The shared library, or None (then everything goes through zlib)."""
+    global _lib, _lib_tried
+    if not _lib_tried:
+        _lib_tried = True
+        for name in ("libdeflate.so.0", "libdeflate.so"):
+            try:
+                L = C.CDLL(name)
+            except OSError:
+                continue
+            L.libdeflate_alloc_compressor.restype = C.c_void_p
+            L.libdeflate_alloc_compressor.argtypes = [C.c_int]
+            L.libdeflate_gzip_compress.restype = C.c_size_t
+            L.libdeflate_gzip_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+            L.libdeflate_gzip_compress_bound.restype = C.c_size_t
+            L.libdeflate_gzip_compress_bound.argtypes = [C.c_void_p, C.c_size_t]
+            L.libdeflate_alloc_decompressor.restype = C.c_void_p
+            L.libdeflate_gzip_decompress_ex.restype = C.c_int
+            L.libdeflate_gzip_decompress_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                        C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+            _lib = L
+            break
+    return _lib
+
+
+def _view_address(mv: memoryview) -> int:
+    import numpy as np
+    return np.frombuffer(mv, dtype=np.uint8).ctypes.data
+
+
+def gzip_member(data, level: int = 1) -> bytes:
+    """``data`` (bytes-like) as one complete gzip member."""
+    L = libdeflate()
+    n = len(data)
+    if L is None or n == 0:
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+    comp = getattr(_tls, "comp", None)
+    if comp is None or comp[0] != level:
+        comp = _tls.comp = (level, L.libdeflate_alloc_compressor(level))
+    bound = L.libdeflate_gzip_compress_bound(comp[1], n)
+    out = getattr(_tls, "out", None)
+    if out is None or len(out) < bound:
+        out = _tls.out = bytearray(int(bound * 1.25) + 64)
+    src = data if isinstance(data, bytes) else _view_address(memoryview(data))
+    dst = (C.c_char * len(out)).from_buffer(out)
+    got = L.libdeflate_gzip_compress(comp[1], src, n, dst, len(out))
+    if got == 0:  # cannot happen with a bound-sized buffer; stay correct anyway
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return c.compress(data) + c.flush()
+    return bytes(memoryview(out)[:got])
+
+
+def _decompressor():
+    d = getattr(_tls, "decomp", None)
+    if d is None:
+        d = _tls.decomp = libdeflate().libdeflate_alloc_decompressor()
+    return d
+
+
+def _bgzf_block_size(buf, pos: int) -> int:
+    """Total size of the BGZF block at ``pos`` (0 if the member there is not a BGZF block)."""
+    if pos + 18 > len(buf) or buf[pos:pos + 4] != b"\x1f\x8b\x08\x04":
+        return 0
+    xlen = struct.unpack_from("<H", buf, pos + 10)[0]
+    p, end = pos + 12, pos + 12 + xlen
+    while p + 4 <= end and end <= len(buf):
+        si1, si2, slen = buf[p], buf[p + 1], struct.unpack_from("<H", buf, p + 2)[0]
+        if si1 == 66 and si2 == 67 and slen == 2:
+            return struct.unpack_from("<H", buf, p + 4)[0] + 1
+        p += 4 + slen
+    return 0
+
+
+def _inflate_span(buf, lo: int, hi: int, out_hint: int) -> bytes:
+    """Every member inside buf[lo:hi] (member-aligned), concatenated."""
+    L, d = libdeflate(), _decompressor()
+    base = _view_address(memoryview(buf))
+    out = bytearray(max(out_hint, 1 << 16))
+    used = 0
+    n_in, n_out = C.c_size_t(), C.c_size_t()
+    pos = lo
+    while pos < hi:
+        while True:
+            dst = (C.c_char * (len(out) - used)).from_buffer(out, used)
+            rc = L.libdeflate_gzip_decompress_ex(d, base + pos, hi - pos, dst, len(out) - used, C.byref(n_in),
+                                                 C.byref(n_out))
+            del dst
+            if rc == 3:  # LIBDEFLATE_INSUFFICIENT_SPACE
+                out.extend(bytes(len(out)))
+                continue
+            if rc != 0:
+                raise OSError(f"corrupt gzip data (libdeflate error {rc})")
+            break
+        used += n_out.value
+        pos += n_in.value
+    return bytes(memoryview(out)[:used])
+
+
+class GzipSource:
+    """Decompressed blocks of a gzip file, in order."""
+
+    def __init__(self, path: str, pool=None):
+        self.path = path
+        self.pool = pool
+        self.fh = open(path, "rb")
+        self.size = self.fh.seek(0, 2)
+        self.fh.seek(0)
+        self.map = mmap.mmap(self.fh.fileno(), 0, access=mmap.ACCESS_READ) if self.size else None
+
+    def close(self):
+        if self.map is not None:
+            try:
+                self.map.close()
+            except BufferError:  # a block handed out earlier still points into the map
+                pass
+        self.fh.close()
+
+    def blocks(self) -> Iterator[bytes]:
+        if self.map is None:
+            return
+        if libdeflate() is None:
+            yield from self._zlib_stream(0)
+            return
+        if _bgzf_block_size(self.map, 0):
+            yield from self._bgzf()
+            return
+        yield from self._members()
+
+    # -- BGZF: boundaries are in the headers, spans of blocks inflate in parallel ------------------
+    def _bgzf(self) -> Iterator[bytes]:
+        buf, n = self.map, self.size
+        spans, lo, pos = [], 0, 0
+        while pos < n:
+            size = _bgzf_block_size(buf, pos)
+            if size == 0:  # a foreign member in the middle: the rest goes member by member
+                break
+            pos += size
+            if pos - lo >= (4 << 20):
+                spans.append((lo, pos))
+                lo = pos
+        if pos > lo:
+            spans.append((lo, pos))
+        tail = pos
+        if self.pool is None:
+            for a, b in spans:
+                yield _inflate_span(buf, a, b, 4 * (b - a))
+        else:
+            from collections import deque
+            pending = deque()
+            for a, b in spans:
+                pending.append(self.pool.submit(_inflate_span, buf, a, b, 4 * (b - a)))
+                if len(pending) >= 8:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        if tail < n:
+            yield from self._members(tail)
+
+    # -- generic gzip: one libdeflate call per member ----------------------------------------------
+    def _members(self, start: int = 0) -> Iterator[bytes]:
+        L, d = libdeflate(), _decompressor()
+        buf, n = self.map, self.size
+        base = _view_address(memoryview(buf))
+        n_in, n_out = C.c_size_t(), C.c_size_t()
+        pos = start
+        cap = 32 << 20
+        out = bytearray(cap)
+        while pos < n:
+            if buf[pos] == 0:  # zero padding after the last member (tar-style): done
+                if not any(buf[pos:min(n, pos + 4096)]):
+                    return
+            while True:
+                dst = (C.c_char * len(out)).from_buffer(out)
+                rc = L.libdeflate_gzip_decompress_ex(d, base + pos, n - pos, dst, len(out), C.byref(n_in), C.byref(n_out))
+                del dst
+                if rc == 3 and len(out) < _MEMBER_CAP:
+                    out = bytearray(min(_MEMBER_CAP, 4 * len(out)))
+                    continue
+                break
+            if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
+                yield from self._zlib_stream(pos)
+                return
+            if rc != 0:
+                raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
+            pos += n_in.value
+            yield bytes(memoryview(out)[: n_out.value])
+
+    # -- fallback: zlib streaming, any member size -------------------------------------------------
+    def _zlib_stream(self, start: int) -> Iterator[bytes]:
+        buf, n = self.map, self.size
+        pos = start
+        d = zlib.decompressobj(31)
+        fresh = True  # the current decompressor has not seen a byte yet
+        while pos < n:
+            data = buf[pos:pos + (1 << 20)]
+            pos += len(data)
+            while data:
+                if fresh and data[0] == 0 and not any(data) and not any(buf[pos:min(n, pos + (1 << 20))]):
+                    return  # zero padding behind the last member
+                try:
+                    out = d.decompress(data, _STREAM_BLOCK)
+                except zlib.error as exc:
+                    raise OSError(f"{self.path}: corrupt gzip data ({exc})") from exc
+                fresh = False
+                if out:
+                    yield out
+                if d.eof:
+                    data = d.unused_data
+                    d = zlib.decompressobj(31)
+                    fresh = True
+                else:
+                    data = d.unconsumed_tail
+        if not fresh:
+            raise OSError(f"{self.path}: truncated gzip stream")
+
+
+def is_gzip(path: str) -> bool:
+    with open(path, "rb") as fh:
+        return fh.read(2) == b"\x1f\x8b"

@@ -564,9 +564,10 @@ int cs_sync(cs_engine *eng, uint32_t slot) {
 int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset) {
   if (!eng || !stats) return fail(CS_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(eng->device));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(stats, eng->d_stats, 2 * sizeof(cs_stats), hipMemcpyDeviceToHost));
-  if (reset) HIP_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
+  // the engine's own stream; launches on a caller's stream (cs_trim_device) are the caller's to order
+  HIP_TRY(hipMemcpyAsync(stats, eng->d_stats, 2 * sizeof(cs_stats), hipMemcpyDeviceToHost, eng->stream));
+  if (reset) HIP_TRY(hipMemsetAsync(eng->d_stats, 0, 2 * sizeof(cs_stats), eng->stream));
+  HIP_TRY(hipStreamSynchronize(eng->stream));
   return CS_OK;
 }
 
@@ -581,7 +582,7 @@ int cs_last_kernel_ms(cs_engine *eng, float *ms) {
 
 void *cs_alloc_pinned(size_t bytes) {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {  // usable by every GPU of the node
     fail(CS_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
     return nullptr;
   }

@@ -67,18 +67,39 @@ class TrimEngine:
         r.cap2 = cap2.ctypes.data if cap2 is not None else None
         return r
 
-    def submit(self, slot: int, seq1, qual1, len1, seq2=None, qual2=None, len2=None):
-        """Asynchronous: returns the (still being filled) result arrays; call ``wait(slot)``."""
+    @staticmethod
+    def _check_mate(name, seq, qual, lens, n, stride):
+        """The C ABI trusts its arrays (include/cutseq_hip.h, data contract): refuse anything else here."""
+        for label, a in ((f"seq{name}", seq), (f"qual{name}", qual)):
+            if not isinstance(a, np.ndarray) or a.dtype != np.uint8 or a.shape != (n, stride) or not a.flags.c_contiguous:
+                raise ValueError(f"{label}: expected a C-contiguous uint8 array of shape ({n}, {stride})")
+        if not isinstance(lens, np.ndarray) or lens.dtype != np.uint16 or lens.shape != (n,) or not lens.flags.c_contiguous:
+            raise ValueError(f"len{name}: expected a C-contiguous uint16 array of shape ({n},)")
+        if n and int(lens.max()) > stride:
+            raise ValueError(f"len{name}: a read is longer than the row stride {stride}")
+
+    def submit(self, slot: int, seq1, qual1, len1, seq2=None, qual2=None, len2=None, out=None):
+        """Asynchronous: returns the (still being filled) result arrays; call ``wait(slot)``.
+        ``out``: optional (res1, cap2 | None, res2 | None) arrays to fill (e.g. pinned memory)."""
+        if seq1.ndim != 2:
+            raise ValueError("seq1: expected a 2-D array [n_reads, stride]")
         n, stride = seq1.shape
-        for a in (seq1, qual1) + ((seq2, qual2) if seq2 is not None else ()):
-            assert a.dtype == np.uint8 and a.flags.c_contiguous and a.shape == (n, stride)
-        out1 = np.empty(n, dtype=abi.RESULT_DTYPE)
-        cap2 = np.empty(n, dtype=abi.CAP2_DTYPE) if self.plan.needs_cap2 else None
+        if stride % 4:
+            raise ValueError(f"row stride {stride} is not a multiple of 4")
+        self._check_mate(1, seq1, qual1, len1, n, stride)
+        if (seq2 is not None) != self.plan.paired:
+            raise ValueError("plan is %s-end" % ("paired" if self.plan.paired else "single"))
+        if seq2 is not None:
+            self._check_mate(2, seq2, qual2, len2, n, stride)
+        if out is not None:
+            out1, cap2, out2 = out
+        else:
+            out1 = np.empty(n, dtype=abi.RESULT_DTYPE)
+            cap2 = np.empty(n, dtype=abi.CAP2_DTYPE) if self.plan.needs_cap2 else None
+            out2 = np.empty(n, dtype=abi.RESULT_DTYPE) if seq2 is not None else None
         r1 = self._reads(seq1, qual1, len1, out1, cap2)
-        out2 = None
         r2p = None
         if seq2 is not None:
-            out2 = np.empty(n, dtype=abi.RESULT_DTYPE)
             r2 = self._reads(seq2, qual2, len2, out2)
             r2p = C.byref(r2)
         capi.check(self.L.cs_trim_batch(self._eng_h, slot, C.byref(r1), r2p, n, stride))

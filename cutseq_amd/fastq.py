@@ -2,23 +2,23 @@
 formatted records out (tier E of SURVEY.md 8d; counterpart of ``cutadapt.files`` / dnaio /
 xopen as the reference uses them, cutseq/run.py:434-441, 751-758).
 
-Parsing and formatting are native (``csrc/cutseq_host.c``); (de)compression is zlib, which
-releases the GIL, so reader, GPU submission, formatter and the per-file writer threads overlap.
+Parsing and formatting are native (``csrc/cutseq_host.c``), (de)compression is ``codec.py``
+(libdeflate / zlib); all of it releases the GIL, so reader, parser pool, GPU submission, formatter
+and the per-file writer threads overlap.  The arrays that cross PCIe (sequence, quality, lengths,
+results) come from a pinned arena when the caller asks for it (``read_chunks(pinned=True)``).
 """
 from __future__ import annotations
 
 import ctypes as C
-import gzip
 import queue
 import threading
-import zlib
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional, Sequence
 
 import numpy as np
 
-from . import abi
+from . import abi, codec
 from .synth import host_lib as _host_lib
 
 CHUNK_READS = 1 << 16
@@ -56,25 +56,17 @@ def _lib():
     return L
 
 
-def open_input(path: str):
-    """Binary stream of the decompressed file (gzip by magic number, else plain)."""
-    fh = open(path, "rb")
-    magic = fh.read(2)
-    fh.seek(0)
-    if magic == b"\x1f\x8b":
-        return gzip.GzipFile(fileobj=fh, mode="rb")
-    return fh
-
-
 class _Arena:
     """Recycles the big per-chunk buffers.  Fresh memory costs a page fault per 4 KB on first touch --
     more than the parsing and formatting themselves -- so buffers go back here when a chunk is done
     (:meth:`Chunk.release`) and are handed out again, already mapped."""
 
-    def __init__(self, keep_per_size: int = 48):
+    def __init__(self, keep_per_size: int = 48, pinned: bool = False):
         self._lock = threading.Lock()
         self._free: dict = {}
         self._keep = keep_per_size
+        self._pinned = pinned
+        self._all_pinned: list = []  # (address, array) of every pinned buffer ever handed out
 
     @staticmethod
     def _bucket(nbytes: int) -> int:
@@ -87,7 +79,19 @@ class _Arena:
             stack = self._free.get(size)
             if stack:
                 return stack.pop()
-        return np.empty(size, dtype=np.uint8)
+        if not self._pinned:
+            return np.empty(size, dtype=np.uint8)
+        # page-locked host memory (hipHostMalloc through the C ABI): H2D / D2H copies of these buffers are
+        # real DMA transfers that overlap the kernels of the other slot
+        from . import capi
+        L = capi.load()
+        ptr = L.cs_alloc_pinned(size)
+        if not ptr:
+            raise MemoryError(f"cs_alloc_pinned({size}) failed: {L.cs_last_error().decode(errors='replace')}")
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(size,))
+        with self._lock:
+            self._all_pinned.append((ptr, arr))
+        return arr
 
     def give(self, arr: np.ndarray) -> None:
         with self._lock:
@@ -96,7 +100,21 @@ class _Arena:
                 stack.append(arr)
 
 
+    def free_pinned(self) -> None:
+        """Release every pinned buffer (end of a run; nothing may still be using them)."""
+        if not self._pinned:
+            return
+        from . import capi
+        L = capi.load()
+        with self._lock:
+            self._free.clear()
+            for ptr, _ in self._all_pinned:
+                L.cs_free_pinned(ptr)
+            self._all_pinned.clear()
+
+
 ARENA = _Arena()
+PINNED = _Arena(keep_per_size=64, pinned=True)
 
 
 @dataclass
@@ -116,7 +134,7 @@ class Chunk:
     qual2: Optional[np.ndarray] = None
     len2: Optional[np.ndarray] = None
 
-    _owned: tuple = ()  # arena buffers behind the arrays above
+    _owned: tuple = ()  # (arena, buffer) pairs behind the arrays above
 
     @property
     def paired(self) -> bool:
@@ -124,8 +142,8 @@ class Chunk:
 
     def release(self) -> None:
         """Hand the chunk's buffers back for reuse; the chunk must not be touched afterwards."""
-        for arr in self._owned:
-            ARENA.give(arr)
+        for arena, arr in self._owned:
+            arena.give(arr)
         self._owned = ()
 
 
@@ -172,10 +190,13 @@ def _raw_pointer(raw):
     return raw if isinstance(raw, bytes) else np.frombuffer(raw, dtype=np.uint8).ctypes.data
 
 
-def _parse(path: str, raw, n_records: int, stride: int, first_record: int, raw_owner=()) -> _Half:
+def _parse(path: str, raw, n_records: int, stride: int, first_record: int, raw_owner=(), pinned: bool = False) -> _Half:
+    """Native parse of ``n_records`` complete records in ``raw`` into fixed-stride rows."""
     L = _lib()
-    bufs = [ARENA.take(n_records * stride), ARENA.take(n_records * stride), ARENA.take(n_records * 2),
-            ARENA.take(n_records * 8), ARENA.take(n_records * 4)]
+    dev = PINNED if pinned else ARENA  # what crosses PCIe: sequence, quality, lengths
+    owned = [(dev, dev.take(n_records * stride)), (dev, dev.take(n_records * stride)), (dev, dev.take(n_records * 2)),
+             (ARENA, ARENA.take(n_records * 8)), (ARENA, ARENA.take(n_records * 4))]
+    bufs = [b for _, b in owned]
     seq = bufs[0][: n_records * stride].reshape(n_records, stride)
     qual = bufs[1][: n_records * stride].reshape(n_records, stride)
     lens = bufs[2][: n_records * 2].view(np.uint16)
@@ -187,24 +208,27 @@ def _parse(path: str, raw, n_records: int, stride: int, first_record: int, raw_o
         raise FastqFormatError(
             f"{path}: malformed FASTQ record {first_record - rc} "
             "(expected '@' header, sequence, '+' line and a quality line of equal length)")
-    return _Half(n_records, stride, raw, noff, nlen, seq, qual, lens, tuple(bufs) + tuple(raw_owner))
+    return _Half(n_records, stride, raw, noff, nlen, seq, qual, lens, tuple(owned) + tuple(raw_owner))
 
 
 class _Reader:
-    """One input file -> parsed halves of ``chunk_reads`` records, through two threads: one inflates
-    (zlib releases the GIL), one cuts at record boundaries and parses (native code, GIL released too).
-    The consumer only pairs the halves up."""
+    """One input file -> parsed halves of ``chunk_reads`` records.  One thread produces decompressed text
+    (gzip: ``codec.GzipSource``, BGZF blocks inflate in the pool; plain files are read straight into the
+    chunk buffer), one cuts it at record boundaries; the parse of each chunk runs in the shared pool, so
+    several chunks of a file are parsed at once.  The consumer only pairs the halves up."""
 
-    def __init__(self, path: str, chunk_reads: int, hint: _StrideHint):
-        self.path, self.chunk_reads, self.hint = path, chunk_reads, hint
-        self.fh = open_input(path)
+    def __init__(self, path: str, chunk_reads: int, hint: _StrideHint, pinned: bool = False):
+        self.path, self.chunk_reads, self.hint, self.pinned = path, chunk_reads, hint, pinned
+        self.gz = codec.is_gzip(path)
+        self.src = codec.GzipSource(path, _pool()) if self.gz else open(path, "rb", buffering=0)
         self._blocks: "queue.Queue" = queue.Queue(maxsize=4)
-        self.halves: "queue.Queue" = queue.Queue(maxsize=2)
+        self.halves: "queue.Queue" = queue.Queue(maxsize=3)
         self._stop = False
-        self._t1 = threading.Thread(target=self._inflate, daemon=True)
-        self._t2 = threading.Thread(target=self._cut, daemon=True)
-        self._t1.start()
-        self._t2.start()
+        self._threads = [threading.Thread(target=self._cut, daemon=True)]
+        if self.gz:
+            self._threads.append(threading.Thread(target=self._inflate, daemon=True))
+        for t in self._threads:
+            t.start()
 
     def _put(self, q, item) -> bool:
         while not self._stop:
@@ -217,40 +241,51 @@ class _Reader:
 
     def _inflate(self):
         try:
-            while not self._stop:
-                block = self.fh.read(_READ_BLOCK)
-                if not self._put(self._blocks, block) or not block:
-                    break
+            for block in self.src.blocks():
+                if self._stop or not self._put(self._blocks, block):
+                    return
+            self._put(self._blocks, b"")
         except BaseException as exc:
             self._put(self._blocks, _Failure(exc))
 
+    def _fill(self, buf: np.ndarray, fill: int):
+        """More text behind buf[:fill] -> (buf, fill, eof); the buffer grows when it has to."""
+        if self.gz:
+            block = self._blocks.get()
+            if isinstance(block, _Failure):
+                raise block.exc
+            if not block:
+                return buf, fill, True
+            if fill + len(block) > buf.size:
+                bigger = ARENA.take(max(2 * buf.size, fill + len(block)))
+                C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
+                ARENA.give(buf)
+                buf = bigger
+            C.memmove(buf.ctypes.data + fill, block, len(block))
+            return buf, fill + len(block), False
+        if buf.size - fill < _READ_BLOCK:
+            bigger = ARENA.take(max(2 * buf.size, fill + _READ_BLOCK))
+            C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
+            ARENA.give(buf)
+            buf = bigger
+        got = self.src.readinto(memoryview(buf)[fill:fill + _READ_BLOCK])  # page cache -> chunk buffer, one copy
+        return buf, fill + (got or 0), not got
+
     def _cut(self):
         L = _lib()
-        # inflated blocks are appended to an arena buffer with ctypes.memmove (GIL released): the
-        # buffer becomes the chunk's raw text, only the short tail behind the last complete record
-        # moves on to the next one
+        # text is appended to an arena buffer; the buffer becomes the chunk's raw text, only the short tail
+        # behind the last complete record moves on to the next one
         buf = ARENA.take(4 * _READ_BLOCK)
         fill = 0
         eof = False
         done = 0       # records handed out so far
         need = 0       # bytes worth buffering before the next count (from the previous chunk's density)
         consumed, longest = C.c_int64(), C.c_int32()
+        pool = _pool()
         try:
             while not self._stop:
                 while not eof and fill < max(need, 1):
-                    block = self._blocks.get()
-                    if isinstance(block, _Failure):
-                        raise block.exc
-                    if not block:
-                        eof = True
-                        break
-                    if fill + len(block) > buf.size:
-                        bigger = ARENA.take(max(2 * buf.size, fill + len(block)))
-                        C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
-                        ARENA.give(buf)
-                        buf = bigger
-                    C.memmove(buf.ctypes.data + fill, block, len(block))
-                    fill += len(block)
+                    buf, fill, eof = self._fill(buf, fill)
                 n = L.csh_fastq_count(buf.ctypes.data, fill, self.chunk_reads, 1 if eof else 0, C.byref(consumed),
                                       C.byref(longest)) if fill else 0
                 if n < self.chunk_reads and not eof:
@@ -267,11 +302,11 @@ class _Reader:
                 C.memmove(nxt.ctypes.data, buf.ctypes.data + used, fill - used)
                 raw = memoryview(buf)[:used]  # compares equal to bytes, slices without copying
                 stride = self.hint.raise_to(int(longest.value))
-                half = _parse(self.path, raw, int(n), stride, done, raw_owner=(buf,))
+                job = pool.submit(_parse, self.path, raw, int(n), stride, done, ((ARENA, buf),), self.pinned)
                 buf, fill = nxt, fill - used
                 done += int(n)
                 need = used + (used >> 6)  # the next chunk will be about as long
-                if not self._put(self.halves, half):
+                if not self._put(self.halves, job):
                     return
         except BaseException as exc:
             self._put(self.halves, _Failure(exc))
@@ -280,7 +315,7 @@ class _Reader:
         item = self.halves.get()
         if isinstance(item, _Failure):
             raise item.exc
-        return item
+        return item.result() if item is not None else None
 
     def close(self):
         self._stop = True
@@ -290,23 +325,24 @@ class _Reader:
                     q.get_nowait()
             except queue.Empty:
                 pass
-        self.fh.close()
+        self.src.close()
 
 
-def _restride(path: str, half: _Half, stride: int, first_record: int) -> _Half:
+def _restride(path: str, half: _Half, stride: int, first_record: int, pinned: bool) -> _Half:
     if half.stride == stride:
         return half
-    again = _parse(path, half.raw, half.n, stride, first_record, raw_owner=half.owned[5:])
-    for arr in half.owned[:5]:
-        ARENA.give(arr)
+    again = _parse(path, half.raw, half.n, stride, first_record, raw_owner=half.owned[5:], pinned=pinned)
+    for arena, arr in half.owned[:5]:
+        arena.give(arr)
     return again
 
 
-def read_chunks(path1: str, path2: Optional[str] = None, chunk_reads: int = CHUNK_READS):
-    """Yield record-aligned :class:`Chunk` objects (equal record counts for both mates)."""
+def read_chunks(path1: str, path2: Optional[str] = None, chunk_reads: int = CHUNK_READS, pinned: bool = False):
+    """Yield record-aligned :class:`Chunk` objects (equal record counts for both mates).  ``pinned``: the
+    arrays the GPU copies (sequence, quality, lengths) live in page-locked memory (needs the HIP library)."""
     hint = _StrideHint()
-    r1 = _Reader(path1, chunk_reads, hint)
-    r2 = _Reader(path2, chunk_reads, hint) if path2 else None
+    r1 = _Reader(path1, chunk_reads, hint, pinned)
+    r2 = _Reader(path2, chunk_reads, hint, pinned) if path2 else None
     done = 0
     try:
         while True:
@@ -327,7 +363,7 @@ def read_chunks(path1: str, path2: Optional[str] = None, chunk_reads: int = CHUN
                     "Reads are improperly paired! There are more reads in one file than in the other, "
                     "or a record is truncated.")
             stride = max(h1.stride, h2.stride)
-            h1, h2 = _restride(path1, h1, stride, done), _restride(path2, h2, stride, done)
+            h1, h2 = _restride(path1, h1, stride, done, pinned), _restride(path2, h2, stride, done, pinned)
             yield Chunk(h1.n, stride, h1.raw, h1.name_off, h1.name_len, h1.seq, h1.qual, h1.lens,
                         h2.raw, h2.name_off, h2.name_len, h2.seq, h2.qual, h2.lens, _owned=h1.owned + h2.owned)
             done += h1.n
@@ -409,7 +445,7 @@ def finish_chunk(chunk: Chunk, plan, res1, cap2, res2, gz: Sequence[Sequence[Opt
         for m in range(2):
             if gz[r][m] is None or len(views[r][m]) == 0:
                 continue
-            blobs[r][m] = _gzip_member(views[r][m], level) if gz[r][m] else bytes(views[r][m])
+            blobs[r][m] = codec.gzip_member(views[r][m], level) if gz[r][m] else bytes(views[r][m])
     return blobs, counts
 
 
@@ -429,11 +465,6 @@ def _pool():
     return _POOL
 
 
-def _gzip_member(data, level: int) -> bytes:
-    c = zlib.compressobj(level, zlib.DEFLATED, 31)
-    return c.compress(data) + c.flush()
-
-
 class OutputFile:
     """One output file.  ``.gz`` names are written as a sequence of gzip members (level 1 =
     cutadapt's default), one member per block, compressed in a shared thread pool and written
@@ -451,39 +482,48 @@ class OutputFile:
         self.t.start()
 
     def _run(self):
-        try:
-            while True:
-                item = self.q.get()
-                if item is None:
-                    break
+        while True:
+            item = self.q.get()
+            if item is None:
+                break
+            if self.err is not None:
+                continue  # after a failure: keep draining so that producers never block on a dead consumer
+            try:
                 if isinstance(item, tuple):  # (future of finish_chunk, route, mate)
                     blob = item[0].result()[0][item[1]][item[2]]
                     if blob:
                         self.fh.write(blob)
                 else:
                     self.fh.write(item.result() if self.gz else item)
-        except BaseException as exc:  # pragma: no cover
-            self.err = exc
-        finally:
+            except BaseException as exc:
+                self.err = exc
+        try:
             self.fh.close()
+        except BaseException as exc:  # pragma: no cover
+            self.err = self.err or exc
+
+    def _check(self):
+        if self.err is not None:
+            raise self.err
 
     def write(self, data: bytes):
+        self._check()
         if not data:
             return
         if self.gz:
-            self.q.put(_pool().submit(_gzip_member, data, self.level))
+            self.q.put(_pool().submit(codec.gzip_member, data, self.level))
         else:
             self.q.put(data)
 
     def write_job(self, future, route: int, mate: int):
         """Queue the (route, mate) stream of a :func:`finish_chunk` job; written when the job is done."""
+        self._check()
         self.q.put((future, route, mate))
 
     def close(self):
         self.q.put(None)
         self.t.join()
-        if self.gz and self.fh.closed and Path(self.path).stat().st_size == 0:
+        if self.err is None and self.gz and Path(self.path).stat().st_size == 0:
             with open(self.path, "wb") as fh:  # an empty stream is still a valid gzip file
-                fh.write(_gzip_member(b"", self.level))
-        if self.err:
-            raise self.err
+                fh.write(codec.gzip_member(b"", self.level))
+        self._check()

@@ -76,14 +76,24 @@ def first_adapter(chain: Optional[MateChain]):
     return None, None
 
 
+def add_stats(a: dict, b: dict) -> dict:
+    """Sum of two ``cs_stats.as_dict()`` blocks (one device's counters over several engines)."""
+    out = {}
+    for key, va in a.items():
+        vb = b[key]
+        out[key] = [x + y for x, y in zip(va, vb)] if isinstance(va, list) else va + vb
+    return out
+
+
 def _mate_sum(totals: dict, mate: int, field: str) -> int:
-    return sum(int(getattr(pair[mate], field)) for pair in totals["stats"])
+    """``totals["stats"]``: one [mate 1, mate 2] pair of ``cs_stats.as_dict()`` blocks per device worker."""
+    return sum(int(pair[mate][field]) for pair in totals["stats"])
 
 
 def _matched(totals: dict, mate: int, slot: Optional[int]) -> int:
     if slot is None:
         return 0
-    return sum(int(pair[mate].op_matched[slot]) for pair in totals["stats"])
+    return sum(int(pair[mate]["op_matched"][slot]) for pair in totals["stats"])
 
 
 def minimal_report(tp: TrimPlan, totals: dict) -> str:
@@ -134,7 +144,7 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
         "cutadapt_version": None,  # no cutadapt in this engine
         "engine": {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
                    "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
-                   "per_device": [[s.as_dict() for s in pair] for pair in totals["stats"]]},
+                   "per_device": totals["stats"]},
         "input": {"path1": input1, "path2": input2, "paired": True if input2 else False},
         "output": {"output1": output1, "output2": output2, "short1": short1, "short2": short2,
                    "untrimmed1": untrimmed1, "untrimmed2": untrimmed2},

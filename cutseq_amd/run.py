@@ -14,8 +14,10 @@ from __future__ import annotations
 import argparse
 import logging
 import os
+import queue
 import re
 import sys
+import threading
 import time
 from collections import deque
 from typing import List, Optional
@@ -80,61 +82,67 @@ def build_parser() -> argparse.ArgumentParser:
     return p
 
 
-def _output_names(output_files, input_files, output_prefix, output_suffix):
-    """reference: validate_output_file (run.py:1058-1086)."""
-    default_format = ".fastq.gz"
-    r1_suffix = "_" + output_suffix + "_R1" + default_format
-    r2_suffix = "_" + output_suffix + "_R2" + default_format
-    if output_files:
-        if len(output_files) != len(input_files):
-            logging.error(
-                f"Number of {output_suffix} output files ({len(output_files)}) must match number of input files ({len(input_files)})."
-            )
-            sys.exit(1)
-        return output_files
-    if output_prefix is not None:
-        if len(input_files) == 1:
-            return [output_prefix + r1_suffix]
-        return [output_prefix + r1_suffix, output_prefix + r2_suffix]
-    if len(input_files) == 1:
-        return [remove_fq_suffix(input_files[0]) + r1_suffix]
-    return [remove_fq_suffix(input_files[0]) + r1_suffix, remove_fq_suffix(input_files[1]) + r2_suffix]
+# Output naming (user-visible contract of the reference CLI, run.py:1058-1107): for every output class the
+# files are, in this order of precedence, the ones given on the command line (one per input file), the
+# -O prefix, or the input name without its FASTQ suffix, followed by "_<class>_R<mate>.fastq.gz".
+OUTPUT_CLASSES = (  # (argparse attribute, word in the file name)
+    ("output_file", "trimmed"),
+    ("short_file", "short"),
+    ("untrimmed_file", "untrimmed"),
+)
+_SCHEME_HAS_INLINE = re.compile(r".*\([ATGCatgc]+\).*")
+
+
+def _fail(message: str):
+    logging.error(message)
+    sys.exit(1)
+
+
+def output_paths(given, inputs, prefix, word):
+    """File names of one output class, one per input file."""
+    if given:
+        if len(given) != len(inputs):
+            _fail(f"Number of {word} output files ({len(given)}) must match number of input files ({len(inputs)}).")
+        return list(given)
+    stems = [prefix] * len(inputs) if prefix is not None else [remove_fq_suffix(name) for name in inputs]
+    return [f"{stem}_{word}_R{mate}.fastq.gz" for mate, stem in enumerate(stems, 1)]
+
+
+def resolve_scheme(args) -> str:
+    """-a wins over -A; -A looks the preset up case-insensitively and, like the reference, falls back to
+    reading an unknown name as a scheme (run.py:1041-1056)."""
+    scheme = args.adapter_scheme
+    if args.adapter_name is not None and scheme is not None:
+        logging.info("Adapter scheme is provided, ignoring adapter name.")
+    elif args.adapter_name is not None:
+        scheme = BUILDIN_ADAPTERS.get(args.adapter_name.upper())
+        if scheme is None:
+            logging.error(f"Adapter name '{args.adapter_name} not found in built-in adapters.")
+            scheme = args.adapter_name
+    if scheme is None:
+        _fail("Adapter scheme or name is required. Use -a or -A.")
+    return scheme.replace(" ", "").upper()
 
 
 def resolve_args(args):
-    """Everything main() does between parse_args and run_cutseq (run.py:1029-1107)."""
+    """What the reference's main() settles between parse_args and run_cutseq (run.py:1029-1107)."""
     if args.list_adapters:
         print_builtin_adapters()
         sys.exit(0)
-    if args.input_file is None:
-        logging.error("Input file is required.")
-        sys.exit(1)
-    elif len(args.input_file) > 2:
-        logging.error("Input file can not be more than two.")
-        sys.exit(1)
-    if args.adapter_name is not None:
-        if args.adapter_scheme is not None:
-            logging.info("Adapter scheme is provided, ignoring adapter name.")
+    inputs = args.input_file or []
+    if len(inputs) > 2:
+        _fail("Input file can not be more than two.")
+    args.adapter_scheme = resolve_scheme(args)
+    if not inputs:
+        # the reference dies with an IndexError here (run.py:1079-1083); same exit class, clearer message
+        _fail("Input file is required.")
+    wants_untrimmed = bool(args.untrimmed_file) or (
+        args.ensure_inline_barcode and _SCHEME_HAS_INLINE.match(args.adapter_scheme) is not None)
+    for attr, word in OUTPUT_CLASSES:
+        if attr == "untrimmed_file" and not wants_untrimmed:
+            args.untrimmed_file = [None] * len(inputs)
         else:
-            args.adapter_scheme = BUILDIN_ADAPTERS.get(args.adapter_name.upper())
-            if args.adapter_scheme is None:
-                logging.error(f"Adapter name '{args.adapter_name} not found in built-in adapters.")
-                args.adapter_scheme = args.adapter_name  # the reference falls back to using the name as scheme
-    elif args.adapter_scheme is None:
-        logging.error("Adapter scheme or name is required. Use -a or -A.")
-        sys.exit(1)
-    args.adapter_scheme = args.adapter_scheme.replace(" ", "").upper()
-    if len(args.input_file) == 0:
-        # the reference raises IndexError here (run.py:1079-1083); same exit class, clearer message
-        logging.error("Input file is required.")
-        sys.exit(1)
-    args.output_file = _output_names(args.output_file, args.input_file, args.output_prefix, "trimmed")
-    args.short_file = _output_names(args.short_file, args.input_file, args.output_prefix, "short")
-    has_inline = re.match(r".*\([ATGCatgc]+\).*", args.adapter_scheme) is not None
-    if args.untrimmed_file or (args.ensure_inline_barcode and has_inline):
-        args.untrimmed_file = _output_names(args.untrimmed_file, args.input_file, args.output_prefix, "untrimmed")
-    else:
-        args.untrimmed_file = [None] * len(args.input_file)
+            setattr(args, attr, output_paths(getattr(args, attr), inputs, args.output_prefix, word))
     return args
 
 
@@ -182,16 +190,102 @@ def dry_run(tp: TrimPlan, barcode: BarcodeConfig):
             print(f"Step {i + 2}: ReverseComplementConverter()")
 
 
+class _DeviceWorker(threading.Thread):
+    """One GPU: owns the device's TrimEngine, keeps ``SLOTS`` chunks in flight on it (the H2D copy of one
+    overlaps the kernels and the D2H copy of the other) and reports every finished chunk to ``done``.
+    Counterpart of one worker process of ``make_runner(inpaths, cores=N)`` (cutseq/run.py:436, 753)."""
+
+    SLOTS = 2
+
+    def __init__(self, tp: TrimPlan, device: int, done: "queue.Queue", chunk_reads: int):
+        super().__init__(daemon=True, name=f"cutseq-gpu{device}")
+        self.tp, self.device, self.done, self.chunk_reads = tp, device, done, chunk_reads
+        self.inbox: "queue.Queue" = queue.Queue(maxsize=self.SLOTS)
+        self.engine = None
+        self.stride_cap = 0
+        self.stats = None  # summed cs_stats of every engine this device has had
+        self.error: Optional[BaseException] = None
+
+    def _collect_stats(self):
+        part = [s.as_dict() for s in self.engine.stats()]
+        self.stats = part if self.stats is None else [report.add_stats(a, b) for a, b in zip(self.stats, part)]
+
+    def _engine_for(self, stride: int, inflight: deque):
+        """The engine, rebuilt with longer rows when a chunk needs them -- after everything the old one still
+        has in flight came back and its counters were saved."""
+        if self.engine is not None and stride <= self.stride_cap:
+            return
+        from .engine import TrimEngine
+        while inflight:
+            self._finish_oldest(inflight)
+        if self.engine is not None:
+            self._collect_stats()
+            self.engine.close()
+        self.stride_cap = max(stride, 152)
+        self.engine = TrimEngine(self.tp, device=self.device, slots=self.SLOTS, max_reads=self.chunk_reads,
+                                 max_stride=self.stride_cap)
+
+    def _finish_oldest(self, inflight: deque):
+        k, slot, chunk, res = inflight.popleft()
+        self.engine.wait(slot)
+        self.done.put((k, chunk, res))
+
+    def run(self):
+        from . import fastq
+        inflight: deque = deque()  # (chunk index, slot, chunk, result arrays), oldest first
+        n = 0
+        try:
+            while True:
+                item = self.inbox.get()
+                if item is None:
+                    break
+                k, chunk = item
+                self._engine_for(chunk.stride, inflight)
+                if len(inflight) == self.SLOTS:
+                    self._finish_oldest(inflight)  # frees exactly the slot this chunk takes
+                paired = chunk.paired
+                # result arrays in pinned memory, like the inputs: the D2H copy is a DMA transfer too
+                owned = [fastq.PINNED.take(chunk.n * 8)]
+                out1 = owned[0][: chunk.n * 8].view(abi.RESULT_DTYPE)
+                cap2 = out2 = None
+                if self.tp.needs_cap2:
+                    owned.append(fastq.PINNED.take(chunk.n * 4))
+                    cap2 = owned[-1][: chunk.n * 4].view(abi.CAP2_DTYPE)
+                if paired:
+                    owned.append(fastq.PINNED.take(chunk.n * 8))
+                    out2 = owned[-1][: chunk.n * 8].view(abi.RESULT_DTYPE)
+                chunk._owned = chunk._owned + tuple((fastq.PINNED, b) for b in owned)
+                slot = n % self.SLOTS
+                res = self.engine.submit(slot, chunk.seq1, chunk.qual1, chunk.len1, chunk.seq2, chunk.qual2,
+                                         chunk.len2, out=(out1, cap2, out2))
+                inflight.append((k, slot, chunk, res))
+                n += 1
+            while inflight:
+                self._finish_oldest(inflight)
+            if self.engine is not None:
+                self._collect_stats()
+        except BaseException as exc:
+            self.error = exc
+        finally:
+            if self.engine is not None:
+                self.engine.close()
+            self.done.put(self)  # "this device is finished" (or failed)
+
+
 def run_pipeline(args, tp: TrimPlan) -> dict:
-    """Stream the input through the GPU engine(s); returns the run statistics."""
+    """Stream the input through the GPU engine(s); returns the run statistics.
+
+    Counterpart of ``runner.run(pipeline, Progress(), outfiles)`` (cutseq/run.py:473, 794): chunks of
+    ``fastq.CHUNK_READS`` records go round-robin to one worker thread per GPU, come back in any order and are
+    formatted / compressed / written strictly in input order."""
     from . import capi, fastq
-    from .engine import TrimEngine
 
     n_dev = capi.device_count()
     if n_dev <= 0:
         raise capi.HipUnavailable("no HIP device visible; cutseq_amd has no CPU trimming path")
-    want = os.environ.get("CUTSEQ_DEVICES")
+    want = os.environ.get("CUTSEQ_DEVICES")  # e.g. "0,1,2,3"; a device may be listed twice (two engines on it)
     devices = [int(x) for x in want.split(",")] if want else list(range(n_dev))
+    chunk_reads = int(os.environ.get("CUTSEQ_CHUNK_READS", fastq.CHUNK_READS))
     paired = tp.paired
     in1 = args.input_file[0]
     in2 = args.input_file[1] if paired else None
@@ -205,31 +299,19 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     if paired and tp.swap_outputs:
         trimmed = trimmed[::-1]
     outs = [trimmed, mk(args.short_file), mk(args.untrimmed_file)]
-
-    engines = {}
-    stride_cap = {}
-    slots_per_engine = 2
-    inflight = deque()  # (engine, slot, chunk, result arrays): on the GPU
-    finishing = deque()  # futures of fastq.finish_chunk, in chunk order
-    totals = report.new_totals()
-    t0 = time.perf_counter()
     # which (route, mate) streams go to disk, and whether they are gzip
     gz = [[(fh.gz if fh is not None else None) for fh in (group + [None])[:2]] for group in outs]
+
+    totals = report.new_totals()
+    t0 = time.perf_counter()
     pool = fastq._pool()
     max_finishing = fastq.pool_size() + 2  # chunks being formatted / compressed (about 90 MB each)
-
-    def engine_for(dev, stride):
-        eng = engines.get(dev)
-        if eng is None or stride_cap[dev] < stride:
-            if eng is not None:
-                eng.close()
-            cap = max(stride, 152)
-            eng = TrimEngine(tp, device=dev, slots=slots_per_engine, max_reads=fastq.CHUNK_READS, max_stride=cap)
-            engines[dev], stride_cap[dev] = eng, cap
-        return eng
+    done: "queue.Queue" = queue.Queue()
+    workers = [_DeviceWorker(tp, dev, done, chunk_reads) for dev in devices]
+    failure: List[BaseException] = []
 
     def finish(chunk, r1, cap2, r2):
-        """Worker thread: records -> bytes on their way to disk; also this chunk's share of the report."""
+        """Pool job: records -> bytes on their way to disk; also this chunk's share of the report."""
         try:
             blobs, counts = fastq.finish_chunk(chunk, tp, r1, cap2, r2, gz)
             part = report.new_totals()
@@ -239,57 +321,94 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
         finally:
             chunk.release()
 
-    def reap(block: bool):
-        while finishing and (block or finishing[0].done()):
-            _, part = finishing.popleft().result()
-            report.merge_totals(totals, part)
-            block = False
+    def collect():
+        """Re-establishes the input order behind the GPUs and feeds the writers."""
+        waiting, next_k, alive = {}, 0, len(workers)
+        finishing: deque = deque()
+        try:
+            while alive or waiting:
+                item = done.get()
+                if isinstance(item, _DeviceWorker):
+                    alive -= 1
+                    if item.error is not None:
+                        raise item.error
+                    continue
+                waiting[item[0]] = item
+                while next_k in waiting:
+                    _, chunk, (r1, cap2, r2) = waiting.pop(next_k)
+                    next_k += 1
+                    fut = pool.submit(finish, chunk, r1, cap2, r2)
+                    for route in range(3):
+                        for m in range(2 if paired else 1):
+                            if outs[route][m] is not None:
+                                outs[route][m].write_job(fut, route, m)
+                    finishing.append(fut)
+                    while finishing and (len(finishing) >= max_finishing or finishing[0].done()):
+                        report.merge_totals(totals, finishing.popleft().result()[1])
+                if not alive and waiting and next_k not in waiting:
+                    raise RuntimeError("a chunk went missing between the GPU workers and the writer")
+            while finishing:
+                report.merge_totals(totals, finishing.popleft().result()[1])
+        except BaseException as exc:
+            failure.append(exc)
 
-    def drain_one():
-        eng, slot, chunk, res = inflight.popleft()
-        eng.wait(slot)
-        r1, cap2, r2 = res
-        fut = pool.submit(finish, chunk, r1, cap2, r2)
-        for route in range(3):
-            for m in range(2 if paired else 1):
-                fh = outs[route][m]
-                if fh is not None:
-                    fh.write_job(fut, route, m)
-        finishing.append(fut)
-        reap(len(finishing) >= max_finishing)
-
+    collector = threading.Thread(target=collect, daemon=True, name="cutseq-collect")
+    for w in workers:
+        w.start()
+    collector.start()
+    first_error: Optional[BaseException] = None
     try:
-        k = 0
-        for chunk in fastq.read_chunks(in1, in2):
+        for k, chunk in enumerate(fastq.read_chunks(in1, in2, chunk_reads, pinned=True)):
+            if failure:
+                break
             if chunk.stride > abi.CS_MAX_STRIDE:
-                raise ValueError(f"reads longer than {abi.CS_MAX_STRIDE} nt are not supported by the GPU tile")
-            dev = devices[k % len(devices)]
-            slot = (k // len(devices)) % slots_per_engine
-            while len(inflight) >= len(devices) * slots_per_engine:
-                drain_one()
-            # a slot that is still in flight on this engine must be drained before reuse
-            while any(e is engines.get(dev) and sl == slot for e, sl, _, _ in inflight):
-                drain_one()
-            eng = engine_for(dev, chunk.stride)
-            res = eng.submit(slot, chunk.seq1, chunk.qual1, chunk.len1, chunk.seq2, chunk.qual2, chunk.len2)
-            inflight.append((eng, slot, chunk, res))
-            k += 1
-        while inflight:
-            drain_one()
-        while finishing:
-            reap(True)
-        stats = [e.stats() for e in engines.values()]
+                raise ReadTooLong(f"reads longer than {abi.CS_MAX_STRIDE} nt are not supported by the GPU tile "
+                                  f"(record {k * chunk_reads + int(chunk.len1.argmax()) + 1} or its mate)")
+            w = workers[k % len(workers)]
+            while not failure:
+                try:
+                    w.inbox.put((k, chunk), timeout=0.2)
+                    break
+                except queue.Full:
+                    continue
+    except BaseException as exc:
+        first_error = exc
     finally:
-        for e in engines.values():
-            e.close()
+        for w in workers:
+            while True:  # the sentinel must get in even when the worker died with a full inbox
+                try:
+                    w.inbox.put(None, timeout=0.2)
+                    break
+                except queue.Full:
+                    if not w.is_alive():
+                        break
+        for w in workers:
+            w.join()
+        collector.join()
         for group in outs:
             for fh in group:
-                if fh is not None:
+                if fh is None:
+                    continue
+                try:
                     fh.close()
+                except BaseException as exc:  # keep closing the others; report the first failure
+                    first_error = first_error or exc
+        fastq.PINNED.free_pinned()
+    if first_error is None and failure:
+        first_error = failure[0]
+    if first_error is None:
+        first_error = next((w.error for w in workers if w.error is not None), None)
+    if first_error is not None:
+        raise first_error
+    stats = [w.stats for w in workers if w.stats is not None]
     totals["seconds"] = time.perf_counter() - t0
     totals["stats"] = stats
     totals["devices"] = devices
     return totals
+
+
+class ReadTooLong(ValueError):
+    pass
 
 
 def run_cutseq(args):
@@ -319,7 +438,10 @@ def main(argv: Optional[List[str]] = None):
         parser.print_help(sys.stdout)
         sys.exit(0)
     args = resolve_args(parser.parse_args(argv))
-    run_cutseq(args)
+    try:
+        run_cutseq(args)
+    except (ReadTooLong, FileNotFoundError) as exc:  # user errors: the reference's exit style (run.py:1035-1039)
+        _fail(str(exc))
 
 
 if __name__ == "__main__":

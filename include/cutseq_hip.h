@@ -203,7 +203,8 @@ int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_re
 int cs_sync(cs_engine *eng, uint32_t slot);
 
 /* Device-side counters (counterpart of cutadapt's Statistics, run.py:473,794).
- * stats[0] = mate 1, stats[1] = mate 2.  Synchronises the engine stream. */
+ * stats[0] = mate 1, stats[1] = mate 2.  Synchronises the engine's own stream (cs_trim_batch); work a
+ * caller launched on a stream of its own (cs_trim_device) is the caller's to synchronise first. */
 int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset);
 
 /* Timing of the last cs_trim_device launch on its stream, measured with HIP events

@@ -73,3 +73,118 @@ def test_cli_single_end_rc_and_untrimmed(tmp_path):
     assert gunzip(short) == want["short"][0]
     assert gunzip(untr) == want["untrimmed"][0]
     assert len(want["untrimmed"][0]) > 0
+
+
+# ---------------------------------------------------------------- the runner beyond one chunk
+
+
+def crc_streams(streams):
+    import zlib
+    return {k: tuple(None if s is None else (len(s), zlib.crc32(s)) for s in v) for k, v in streams.items()}
+
+
+def oracle_streams(tp, batch, names1, names2):
+    """trimmed / short / untrimmed byte streams from the C oracle's results + the host formatter."""
+    (r1, cap2, _), m2 = util.oracle_run(tp, batch, threads=8)
+    recs = util.format_batch(tp, batch, names1, names2, r1, cap2, m2[0] if m2 else None)
+    out = {}
+    for route, name in enumerate(("trimmed", "short", "untrimmed")):
+        out[name] = (b"".join(x[1] for x in recs if x[0] == route),
+                     b"".join(x[2] for x in recs if x[0] == route) if tp.paired else None)
+    return out
+
+
+def read_streams(prefix, paired, kinds=("trimmed", "short")):
+    return {k: (gunzip(f"{prefix}_{k}_R1.fastq.gz"), gunzip(f"{prefix}_{k}_R2.fastq.gz") if paired else None)
+            for k in kinds}
+
+
+def test_cli_many_chunks_two_engines_on_one_gpu(tmp_path, monkeypatch):
+    """200 000 synthetic pairs = four chunks of 65 536 through TWO engines on GPU 0 (CUTSEQ_DEVICES=0,0):
+    round-robin over the device workers, both staging slots of each engine reused, results re-ordered
+    behind the GPUs.  Input as multi-member gzip.  Streams compared by length + CRC-32 with the oracle's
+    results run through the host formatter (counterpart of make_runner(cores=N), cutseq/run.py:436, 753)."""
+    from cutseq_amd import synth
+    n = 200_000
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    batch = synth.generate_pairs(n, 150, seed=77, poly_fraction=0.05, art5_fraction=0.01, indel_frac=0.1)
+    names1 = [f"SIM:{i} 1:N:0:X".encode() for i in range(n)]
+    names2 = [f"SIM:{i} 2:N:0:X".encode() for i in range(n)]
+    in1, in2 = str(tmp_path / "in_R1.fastq.gz"), str(tmp_path / "in_R2.fastq.gz")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1, gz_members=30_000)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=50_000)
+    monkeypatch.setenv("CUTSEQ_DEVICES", "0,0")
+    prefix = str(tmp_path / "out")
+    cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", prefix, "--json-file", str(tmp_path / "r.json"), in1, in2])
+    got = read_streams(prefix, True)
+    want = oracle_streams(tp, batch, names1, names2)
+    want.pop("untrimmed")
+    assert crc_streams(got) == crc_streams(want)
+    rep = json.loads((tmp_path / "r.json").read_text())
+    assert rep["read_counts"]["input"] == n and rep["engine"]["devices"] == [0, 0]
+    assert len(rep["engine"]["per_device"]) == 2  # both engines saw chunks
+
+
+def test_cli_full_reference_input_in_small_chunks(tmp_path, monkeypatch):
+    """BASELINE.json config 1 at full size: the reference's own 10 000-pair input (tests/golden/fixture10k_*,
+    a copy of test/input_R{1,2}.fq.gz), defaults, in chunks of 1 500 records so that seven chunks cycle
+    through the two staging slots.  Byte for byte against the string-level restatement."""
+    r1, r2 = str(util.GOLDEN / "fixture10k_R1.fq.gz"), str(util.GOLDEN / "fixture10k_R2.fq.gz")
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "1500")
+    prefix = str(tmp_path / "full")
+    cli.main(["-A", "TAKARAV3", "-O", prefix, r1, r2])
+    rec1, rec2 = util.read_fastq_gz(r1), util.read_fastq_gz(r2)
+    assert len(rec1) == len(rec2) == 10_000
+    batch = util.batch_from_records(rec1, rec2)
+    st = planmod.CutadaptConfig()
+    out = util.pyref_run(BUILDIN_ADAPTERS["TAKARAV3"], st, batch, [r[0] for r in rec1], [r[0] for r in rec2])
+    for route, kind in enumerate(("trimmed", "short")):
+        assert gunzip(f"{prefix}_{kind}_R1.fastq.gz") == b"".join(x[1] for x in out if x[0] == route)
+        assert gunzip(f"{prefix}_{kind}_R2.fastq.gz") == b"".join(x[2] for x in out if x[0] == route)
+
+
+def test_cli_longer_reads_appear_in_a_later_chunk(tmp_path, monkeypatch):
+    """The row stride has to grow in the middle of a run (a 300-nt read in the third chunk): the engine is
+    rebuilt only after everything it still has in flight came back, and its counters are kept."""
+    from cutseq_amd import synth
+    n = 6000
+    st = planmod.CutadaptConfig()
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    short = synth.generate_pairs(n, 100, seed=5)
+    long_ = synth.generate_pairs(n, 300, seed=6)
+    reads1, reads2 = [], []
+    for i in range(n):
+        src = long_ if (i >= 2500 and i % 7 == 0) else short
+        reads1.append((util.row_bytes(src.seq1, src.len1, i).decode(), util.row_bytes(src.qual1, src.len1, i).decode()))
+        reads2.append((util.row_bytes(src.seq2, src.len2, i).decode(), util.row_bytes(src.qual2, src.len2, i).decode()))
+    batch = util.batch_from_reads(reads1, reads2)
+    names1 = [f"r{i}/1".encode() for i in range(n)]
+    names2 = [f"r{i}/2".encode() for i in range(n)]
+    in1, in2 = str(tmp_path / "a_R1.fq"), str(tmp_path / "a_R2.fq")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2)
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "1000")
+    prefix = str(tmp_path / "o")
+    cli.main(["-A", "TAKARAV3", "-O", prefix, "--json-file", str(tmp_path / "r.json"), in1, in2])
+    want = oracle_streams(tp, batch, names1, names2)
+    want.pop("untrimmed")
+    assert crc_streams(read_streams(prefix, True)) == crc_streams(want)
+    rep = json.loads((tmp_path / "r.json").read_text())
+    (o1, _, s1), _ = util.oracle_run(tp, batch)
+    # the 5' adapter count of the report comes from the device counters of BOTH engines the run has used
+    assert rep["read_counts"]["read1_with_adapter"] == int(s1.op_matched[0])
+    assert rep["basepair_counts"]["quality_trimmed_read1"] == int(s1.qualtrim_bp)
+
+
+def test_cli_read_longer_than_the_tile_is_a_user_error(tmp_path, caplog):
+    """Reads beyond CS_MAX_STRIDE (1536 nt) are refused the way the reference refuses bad input:
+    logging.error + exit status 1 (cutseq/run.py:1035-1039), not a traceback."""
+    seq = "ACGT" * 500
+    p = tmp_path / "long.fq"
+    p.write_text(f"@x\n{seq}\n+\n{'I' * len(seq)}\n")
+    with pytest.raises(SystemExit) as exc:
+        cli.main([str(p), "-A", "TAKARAV3", "-o", str(tmp_path / "o.fq"), "-s", str(tmp_path / "s.fq")])
+    assert exc.value.code == 1
+    assert "1536" in caplog.text

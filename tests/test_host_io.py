@@ -205,7 +205,7 @@ def test_reports_from_oracle_results():
     want = util.format_batch(tp, batch, [r[0] for r in rec1], [r[0] for r in rec2], r1, cap2, r2)
     for route in range(3):
         totals["routes"][route] = sum(1 for x in want if x[0] == route)
-    totals["stats"] = [(s1, s2)]
+    totals["stats"] = [[s1.as_dict(), s2.as_dict()]]
     totals["devices"], totals["seconds"] = [0], 0.0
 
     def written_bp(mate):

@@ -168,3 +168,20 @@ def soft_mask(batch: SynthBatch, fraction: float = 0.2, seed: int = 9) -> None:
             seg = seq[r, lo:hi]
             letters = (seg >= ord("A")) & (seg <= ord("Z"))
             seg[letters] |= 0x20
+
+
+def write_fastq(path: str, names: Sequence[bytes], batch_seq: np.ndarray, batch_qual: np.ndarray, lens: np.ndarray,
+                gz_members: int = 0) -> None:
+    """Plain-Python FASTQ writer for test inputs.  ``gz_members`` > 0: gzip with that many records per member
+    (a multi-member file, like the CLI's own output); 0: one member (``.gz`` names) or plain text."""
+    recs = []
+    for i, name in enumerate(names):
+        n = int(lens[i])
+        recs.append(b"@" + name + b"\n" + batch_seq[i, :n].tobytes() + b"\n+\n" + batch_qual[i, :n].tobytes() + b"\n")
+    if not path.endswith(".gz"):
+        Path(path).write_bytes(b"".join(recs))
+        return
+    step = gz_members or len(recs) or 1
+    with open(path, "wb") as fh:
+        for lo in range(0, max(len(recs), 1), step):
+            fh.write(gzip.compress(b"".join(recs[lo:lo + step]), 1))
