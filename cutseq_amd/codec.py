@@ -3,7 +3,8 @@ cutseq/run.py:434-441, 751-758).
 
 Output: one gzip member per block, level 1 (cutadapt's default), compressed in the caller's
 thread pool -- libdeflate when ``libdeflate.so.0`` can be loaded, zlib otherwise.
-Input: a stream of decompressed blocks.
+Input: a stream of decompressed blocks, written into recycled buffers (``take`` / ``give`` callbacks:
+fresh memory costs a page fault per 4 KB, more than the inflate itself).
   * BGZF (block boundaries in the headers): blocks inflate in parallel in the pool;
   * any other gzip file: member by member with libdeflate (one call per member, 2-3x zlib's rate;
     multi-member files -- this tool's own output -- never hold more than one member in memory);
@@ -101,37 +102,50 @@ def _bgzf_block_size(buf, pos: int) -> int:
     return 0
 
 
-def _inflate_span(buf, lo: int, hi: int, out_hint: int) -> bytes:
-    """Every member inside buf[lo:hi] (member-aligned), concatenated."""
+def _np_take(nbytes: int):
+    import numpy as np
+    return np.empty(nbytes, dtype=np.uint8)
+
+
+def _np_give(arr) -> None:
+    pass
+
+
+def _inflate_span(buf, lo: int, hi: int, out_hint: int, take=_np_take, give=_np_give):
+    """Every member inside buf[lo:hi] (member-aligned), concatenated -> (uint8 array, bytes used)."""
     L, d = libdeflate(), _decompressor()
     base = _view_address(memoryview(buf))
-    out = bytearray(max(out_hint, 1 << 16))
+    out = take(max(out_hint, 1 << 16))
     used = 0
     n_in, n_out = C.c_size_t(), C.c_size_t()
     pos = lo
     while pos < hi:
         while True:
-            dst = (C.c_char * (len(out) - used)).from_buffer(out, used)
-            rc = L.libdeflate_gzip_decompress_ex(d, base + pos, hi - pos, dst, len(out) - used, C.byref(n_in),
-                                                 C.byref(n_out))
-            del dst
+            rc = L.libdeflate_gzip_decompress_ex(d, base + pos, hi - pos, out.ctypes.data + used, out.size - used,
+                                                 C.byref(n_in), C.byref(n_out))
             if rc == 3:  # LIBDEFLATE_INSUFFICIENT_SPACE
-                out.extend(bytes(len(out)))
+                bigger = take(2 * out.size)
+                C.memmove(bigger.ctypes.data, out.ctypes.data, used)
+                give(out)
+                out = bigger
                 continue
             if rc != 0:
+                give(out)
                 raise OSError(f"corrupt gzip data (libdeflate error {rc})")
             break
         used += n_out.value
         pos += n_in.value
-    return bytes(memoryview(out)[:used])
+    return out, used
 
 
 class GzipSource:
-    """Decompressed blocks of a gzip file, in order."""
+    """Decompressed blocks of a gzip file, in order.  ``blocks()`` yields (buffer, nbytes) pairs: the first
+    ``nbytes`` of the uint8 array are text; the consumer hands the array back with ``give`` when done."""
 
-    def __init__(self, path: str, pool=None):
+    def __init__(self, path: str, pool=None, take=_np_take, give=_np_give):
         self.path = path
         self.pool = pool
+        self.take, self.give = take, give
         self.fh = open(path, "rb")
         self.size = self.fh.seek(0, 2)
         self.fh.seek(0)
@@ -145,7 +159,7 @@ class GzipSource:
                 pass
         self.fh.close()
 
-    def blocks(self) -> Iterator[bytes]:
+    def blocks(self) -> Iterator[tuple]:
         if self.map is None:
             return
         if libdeflate() is None:
@@ -173,12 +187,12 @@ class GzipSource:
         tail = pos
         if self.pool is None:
             for a, b in spans:
-                yield _inflate_span(buf, a, b, 4 * (b - a))
+                yield _inflate_span(buf, a, b, 4 * (b - a), self.take, self.give)
         else:
             from collections import deque
             pending = deque()
             for a, b in spans:
-                pending.append(self.pool.submit(_inflate_span, buf, a, b, 4 * (b - a)))
+                pending.append(self.pool.submit(_inflate_span, buf, a, b, 4 * (b - a), self.take, self.give))
                 if len(pending) >= 8:
                     yield pending.popleft().result()
             while pending:
@@ -187,36 +201,39 @@ class GzipSource:
             yield from self._members(tail)
 
     # -- generic gzip: one libdeflate call per member ----------------------------------------------
-    def _members(self, start: int = 0) -> Iterator[bytes]:
+    def _members(self, start: int = 0) -> Iterator[tuple]:
         L, d = libdeflate(), _decompressor()
         buf, n = self.map, self.size
         base = _view_address(memoryview(buf))
         n_in, n_out = C.c_size_t(), C.c_size_t()
         pos = start
-        cap = 32 << 20
-        out = bytearray(cap)
+        cap = 32 << 20  # grows to the largest member seen so far
         while pos < n:
-            if buf[pos] == 0:  # zero padding after the last member (tar-style): done
-                if not any(buf[pos:min(n, pos + 4096)]):
-                    return
+            if buf[pos] == 0 and not any(buf[pos:min(n, pos + (1 << 20))]):
+                return  # zero padding after the last member (tar-style): done
+            out = self.take(cap)
             while True:
-                dst = (C.c_char * len(out)).from_buffer(out)
-                rc = L.libdeflate_gzip_decompress_ex(d, base + pos, n - pos, dst, len(out), C.byref(n_in), C.byref(n_out))
-                del dst
-                if rc == 3 and len(out) < _MEMBER_CAP:
-                    out = bytearray(min(_MEMBER_CAP, 4 * len(out)))
+                rc = L.libdeflate_gzip_decompress_ex(d, base + pos, n - pos, out.ctypes.data, out.size, C.byref(n_in),
+                                                     C.byref(n_out))
+                if rc == 3 and out.size < _MEMBER_CAP:
+                    self.give(out)
+                    cap = min(_MEMBER_CAP, 4 * cap)
+                    out = self.take(cap)
                     continue
                 break
             if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
+                self.give(out)
                 yield from self._zlib_stream(pos)
                 return
             if rc != 0:
+                self.give(out)
                 raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
             pos += n_in.value
-            yield bytes(memoryview(out)[: n_out.value])
+            yield out, int(n_out.value)
 
     # -- fallback: zlib streaming, any member size -------------------------------------------------
-    def _zlib_stream(self, start: int) -> Iterator[bytes]:
+    def _zlib_stream(self, start: int) -> Iterator[tuple]:
+        import numpy as np
         buf, n = self.map, self.size
         pos = start
         d = zlib.decompressobj(31)
@@ -233,7 +250,7 @@ class GzipSource:
                     raise OSError(f"{self.path}: corrupt gzip data ({exc})") from exc
                 fresh = False
                 if out:
-                    yield out
+                    yield np.frombuffer(out, dtype=np.uint8), len(out)
                 if d.eof:
                     data = d.unused_data
                     d = zlib.decompressobj(31)

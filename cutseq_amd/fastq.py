@@ -10,6 +10,7 @@ results) come from a pinned arena when the caller asks for it (``read_chunks(pin
 from __future__ import annotations
 
 import ctypes as C
+import mmap
 import queue
 import threading
 from dataclasses import dataclass
@@ -23,6 +24,7 @@ from .synth import host_lib as _host_lib
 
 CHUNK_READS = 1 << 16
 _READ_BLOCK = 8 << 20
+_MAP_POPULATE = getattr(mmap, "MAP_POPULATE", 0x8000)
 
 
 class FastqFormatError(ValueError):
@@ -80,7 +82,10 @@ class _Arena:
             if stack:
                 return stack.pop()
         if not self._pinned:
-            return np.empty(size, dtype=np.uint8)
+            # MAP_POPULATE: the kernel maps every page in one call -- touching them one fault at a time is
+            # over ten times slower (and slower than the parsing that fills them)
+            m = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | _MAP_POPULATE)
+            return np.frombuffer(m, dtype=np.uint8)
         # page-locked host memory (hipHostMalloc through the C ABI): H2D / D2H copies of these buffers are
         # real DMA transfers that overlap the kernels of the other slot
         from . import capi
@@ -220,7 +225,8 @@ class _Reader:
     def __init__(self, path: str, chunk_reads: int, hint: _StrideHint, pinned: bool = False):
         self.path, self.chunk_reads, self.hint, self.pinned = path, chunk_reads, hint, pinned
         self.gz = codec.is_gzip(path)
-        self.src = codec.GzipSource(path, _pool()) if self.gz else open(path, "rb", buffering=0)
+        self.src = (codec.GzipSource(path, _pool(), ARENA.take, ARENA.give) if self.gz
+                    else open(path, "rb", buffering=0))
         self._blocks: "queue.Queue" = queue.Queue(maxsize=4)
         self.halves: "queue.Queue" = queue.Queue(maxsize=3)
         self._stop = False
@@ -244,7 +250,7 @@ class _Reader:
             for block in self.src.blocks():
                 if self._stop or not self._put(self._blocks, block):
                     return
-            self._put(self._blocks, b"")
+            self._put(self._blocks, None)
         except BaseException as exc:
             self._put(self._blocks, _Failure(exc))
 
@@ -254,15 +260,18 @@ class _Reader:
             block = self._blocks.get()
             if isinstance(block, _Failure):
                 raise block.exc
-            if not block:
+            if block is None:
                 return buf, fill, True
-            if fill + len(block) > buf.size:
-                bigger = ARENA.take(max(2 * buf.size, fill + len(block)))
+            text, nbytes = block
+            if fill + nbytes > buf.size:
+                bigger = ARENA.take(max(2 * buf.size, fill + nbytes))
                 C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
                 ARENA.give(buf)
                 buf = bigger
-            C.memmove(buf.ctypes.data + fill, block, len(block))
-            return buf, fill + len(block), False
+            C.memmove(buf.ctypes.data + fill, text.ctypes.data, nbytes)
+            if isinstance(text.base, mmap.mmap):  # an arena buffer (zlib fallback blocks are views of bytes objects)
+                ARENA.give(text)
+            return buf, fill + nbytes, False
         if buf.size - fill < _READ_BLOCK:
             bigger = ARENA.take(max(2 * buf.size, fill + _READ_BLOCK))
             C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
@@ -388,11 +397,27 @@ def _out_buffers(cap_bytes: Sequence[int]):
     return bufs
 
 
+class Lease:
+    """The first ``n`` bytes of an arena buffer on their way to a file; whoever writes them gives the buffer back."""
+
+    __slots__ = ("arr", "n")
+
+    def __init__(self, arr: np.ndarray, n: int):
+        self.arr, self.n = arr, n
+
+    def view(self) -> memoryview:
+        return memoryview(self.arr)[: self.n]
+
+    def release(self) -> None:
+        ARENA.give(self.arr)
+
+
 def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray], res2: Optional[np.ndarray],
-                 copy: bool = True):
+                 copy: bool = True, lease=None):
     """-> (data[route][mate], counts[route]) with routes 0 trimmed, 1 short, 2 untrimmed.  ``data`` holds
     ``bytes``; with ``copy=False`` it holds memoryviews into this thread's reusable buffers, valid
-    until the thread formats its next chunk."""
+    until the thread formats its next chunk -- except the streams flagged in ``lease[route][mate]``,
+    which are formatted straight into arena buffers and come back as :class:`Lease` objects."""
     L = _lib()
     fp = _FormatParams()
     fp.paired = 1 if chunk.paired else 0
@@ -409,10 +434,15 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     # + '_' + two captures (<= 510) + "@\n\n+\n\n"
     cap_bytes = [len(chunk.raw1) + 528 * chunk.n + 16, (len(chunk.raw2) + 528 * chunk.n + 16) if chunk.paired else 16]
     bufs = _out_buffers(cap_bytes)
+    leased = [[None, None] for _ in range(3)]
     out_ptrs = ((C.c_void_p * 2) * 3)()
     for r in range(3):
         for m in range(2):
-            out_ptrs[r][m] = bufs[r][m].ctypes.data
+            if lease is not None and lease[r][m] and not copy:
+                leased[r][m] = ARENA.take(cap_bytes[m])
+                out_ptrs[r][m] = leased[r][m].ctypes.data
+            else:
+                out_ptrs[r][m] = bufs[r][m].ctypes.data
     out_len = ((C.c_int64 * 2) * 3)()
     counts = (C.c_int64 * 3)()
     rc = L.csh_format_chunk(
@@ -424,28 +454,40 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
         chunk.seq2.ctypes.data if chunk.paired else None, chunk.qual2.ctypes.data if chunk.paired else None,
         res2.ctypes.data if res2 is not None else None, out_ptrs, out_len, counts)
     if rc < 0:
+        for row in leased:
+            for arr in row:
+                if arr is not None:
+                    ARENA.give(arr)
         i = int(-rc - 1)
         n1 = bytes(chunk.raw1[chunk.name_off1[i]: chunk.name_off1[i] + chunk.name_len1[i]]).decode(errors="replace")
         n2 = bytes(chunk.raw2[chunk.name_off2[i]: chunk.name_off2[i] + chunk.name_len2[i]]).decode(errors="replace")
         raise ValueError(f"Input read IDs not identical: '{n1.split()[0] if n1.split() else n1}' != "
                          f"'{n2.split()[0] if n2.split() else n2}'")
-    views = [[memoryview(bufs[r][m])[: out_len[r][m]] for m in range(2)] for r in range(3)]
+    views = [[(Lease(leased[r][m], int(out_len[r][m])) if leased[r][m] is not None
+               else memoryview(bufs[r][m])[: out_len[r][m]]) for m in range(2)] for r in range(3)]
     if copy:
         return [[bytes(v) for v in row] for row in views], [int(c) for c in counts]
     return views, [int(c) for c in counts]
 
 
 def finish_chunk(chunk: Chunk, plan, res1, cap2, res2, gz: Sequence[Sequence[Optional[bool]]], level: int = 1):
-    """Worker-thread job of the CLI: format one chunk and turn each wanted stream into the bytes that
-    go to disk (one gzip member, or the plain text).  ``gz[route][mate]`` is True / False for
-    compressed / plain outputs and None where no file is open.  -> (blobs[route][mate], counts)."""
-    views, counts = format_chunk(chunk, plan, res1, cap2, res2, copy=False)
+    """Worker-thread job of the CLI: format one chunk and turn each wanted stream into what goes to disk:
+    one gzip member (bytes), or the plain text in an arena buffer (:class:`Lease`).  ``gz[route][mate]`` is
+    True / False for compressed / plain outputs and None where no file is open.
+    -> (blobs[route][mate], counts)."""
+    lease = [[gz[r][m] is False for m in range(2)] for r in range(3)]
+    views, counts = format_chunk(chunk, plan, res1, cap2, res2, copy=False, lease=lease)
     blobs = [[None, None] for _ in range(3)]
     for r in range(3):
         for m in range(2):
-            if gz[r][m] is None or len(views[r][m]) == 0:
-                continue
-            blobs[r][m] = codec.gzip_member(views[r][m], level) if gz[r][m] else bytes(views[r][m])
+            v = views[r][m]
+            if isinstance(v, Lease):
+                if v.n:
+                    blobs[r][m] = v
+                else:
+                    v.release()
+            elif gz[r][m] is not None and len(v):
+                blobs[r][m] = codec.gzip_member(v, level)
     return blobs, counts
 
 
@@ -487,11 +529,24 @@ class OutputFile:
             if item is None:
                 break
             if self.err is not None:
-                continue  # after a failure: keep draining so that producers never block on a dead consumer
+                # after a failure: keep draining so that producers never block on a dead consumer
+                if isinstance(item, tuple):
+                    try:
+                        blob = item[0].result()[0][item[1]][item[2]]
+                        if isinstance(blob, Lease):
+                            blob.release()
+                    except BaseException:
+                        pass
+                continue
             try:
                 if isinstance(item, tuple):  # (future of finish_chunk, route, mate)
                     blob = item[0].result()[0][item[1]][item[2]]
-                    if blob:
+                    if isinstance(blob, Lease):
+                        try:
+                            self.fh.write(blob.view())
+                        finally:
+                            blob.release()
+                    elif blob:
                         self.fh.write(blob)
                 else:
                     self.fh.write(item.result() if self.gz else item)

@@ -20,7 +20,7 @@ def main():
     tp.r1.name_suffixes = ()
     tp.r2.name_suffixes = ()
     outs = [fastq.OutputFile(f"{prefix}_R1.fastq.gz", level), fastq.OutputFile(f"{prefix}_R2.fastq.gz", level)]
-    step = 1 << 18
+    step = fastq.CHUNK_READS  # one gzip member per block, like the CLI's own output
     for lo in range(0, n, step):
         m = min(step, n - lo)
         b = synth.generate_pairs(m, 150, first_index=lo)
