@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (ONE fused kernel launch over both mates) over a
-synthetic batch of ``--pairs`` 2x150 bp read pairs that is already resident in HBM.  The
+A "step" is one pass of the hot path (one cs_trim_device call = scan kernel + resolve kernel over both
+mates) over a synthetic batch of ``--pairs`` 2x150 bp read pairs that is already resident in HBM.  The
 default 25 steps x 4 M pairs = the 100 M-pair workload of BASELINE.json config 3 (TAKARAV3 +
 --trim-polyA: UMI + masks + poly-T/A + q-trim).  Reads shard across ranks with no
 collective (weak scaling: every GPU gets its own 4 M-pair batch); torch.distributed is only
@@ -14,8 +14,13 @@ used for the barrier and the max-over-ranks of the elapsed time.
 
 One JSON line on rank 0, with
   roofline      algorithmic bytes (616 B/pair = 2 x (150 seq + 150 qual + 8 result)) per
-                launch / average kernel time from HIP events on the launch stream, against
-                the 8 TB/s HBM3E peak;
+                launch / average time of the launch's two kernels from HIP events on the launch
+                stream, against the 8 TB/s HBM3E peak; ``traffic`` (HBM bytes per launch) is REPLAYED
+                from the committed counter passes (profiles/r02_pmc_summary.json), not measured in
+                this run;
+  roofline_valu the bound that actually governs: VALU wave-instructions per launch (same replayed
+                counter file) x the measured issue cost per instruction / (1024 SIMDs x clock x
+                kernel time of THIS run);
   cpu_baseline  the CPU oracle (own scalar C restatement of the cutseq->cutadapt chain --
                 cutadapt itself is not installable here) timed on this box's host cores on a
                 bounded sample of the same batch; the GPU results for that sample are
@@ -43,6 +48,12 @@ from cutseq_amd.engine import TrimEngine  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 READ_LEN = 150
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
+# issue cost of one VALU wave-instruction on a SIMD, measured on this part for this kernel's mix of full-
+# and half-rate opcodes (tools/micro/valu_ops.hip): ~85 % at 2.3 cycles, the rest at 4.5
+VALU_CYCLES_PER_INSTR = 2.65
+# BASELINE config 4: inline barcode + 8-nt UMI + dual adapters, --ensure-inline-barcode
+CONFIG4_SCHEME = "ACACGACGCTCTTCCGATCT(ATCACG)NNNNNNNN>AGATCGGAAGAGCACACGTC"
 
 
 def parse_args():
@@ -51,11 +62,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4_000_000, help="read pairs per step (resident batch)")
-    ap.add_argument("--workload", choices=["config3", "config2"], default="config3")
+    ap.add_argument("--workload", choices=["config3", "config2", "config4"], default="config3")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the HBM copy-bandwidth probe")
-    ap.add_argument("--traffic-json", type=str, default=str(ROOT / "profiles" / "r01_pmc_summary.json"),
+    ap.add_argument("--traffic-json", type=str, default=str(ROOT / "profiles" / "r02_pmc_summary.json"),
                     help="JSON with HBM bytes per launch measured in separate rocprofv3 --pmc passes (tools/pmc.sh)")
     return ap.parse_args()
 
@@ -63,6 +74,10 @@ def parse_args():
 def make_plan(workload: str, use_filter: bool):
     if workload == "config2":
         tp = planmod.single_adapter_plan("AGATCGGAAGAGC", 0.1, 3, min_length=0)
+    elif workload == "config4":
+        st = planmod.CutadaptConfig()
+        st.ensure_inline_barcode = True
+        tp = planmod.compile_paired(BarcodeConfig(CONFIG4_SCHEME), st)
     else:
         st = planmod.CutadaptConfig()
         st.trim_polyA = True
@@ -96,11 +111,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    paired = args.workload == "config3"
+    paired = args.workload != "config2"
     tp = make_plan(args.workload, not args.no_filter)
     n = args.pairs
     # every rank trims its own shard of the read stream: global indices rank*n .. rank*n+n
-    if paired:
+    if args.workload == "config4":
+        batch = synth.generate_pairs(n, READ_LEN, CONFIG4_SCHEME, first_index=rank * n)
+    elif paired:
         batch = synth.generate_pairs(n, READ_LEN, first_index=rank * n)
     else:
         batch = synth.generate_single_adapter(n, READ_LEN, first_index=rank * n)
@@ -150,6 +167,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
+    split_ms = eng.last_kernel_split_ms()  # the last step's two kernels (events inside cs_trim_device)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,11 +178,14 @@ def main():
     bytes_per_unit = (2 if paired else 1) * (2 * READ_LEN + 8)
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_per_unit * units_per_step / avg_kernel_s / 1e9
-    traffic = None
-    if paired and args.traffic_json and Path(args.traffic_json).exists():
+    traffic = valu_insts = None
+    traffic_source = None
+    if args.workload == "config3" and args.traffic_json and Path(args.traffic_json).exists():
         pm = json.loads(Path(args.traffic_json).read_text())
         if pm.get("pairs_per_launch") == n:  # counters were collected on this very launch shape
             traffic = pm.get("hbm_bytes_per_launch")
+            valu_insts = pm.get("valu_insts_per_launch")
+            traffic_source = f"replayed from {Path(args.traffic_json).name} (separate rocprofv3 --pmc passes, tools/pmc.sh)"
 
     st1, st2 = eng.stats()
     result = {
@@ -181,12 +202,16 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE config 3: 2x150 bp pairs, full TAKARAV3 scheme + --trim-polyA (UMI+mask+polyT/A+q-trim), "
-                         f"{args.steps} steps x {n} resident pairs per GPU" if paired else
-                         f"BASELINE config 2: 150 bp single-end, 3' adapter AGATCGGAAGAGC e=0.1, {args.steps} steps x {n} reads"),
+            "workload": {
+                "config3": "BASELINE config 3: 2x150 bp pairs, full TAKARAV3 scheme + --trim-polyA (UMI+mask+polyT/A+q-trim), "
+                           f"{args.steps} steps x {n} resident pairs per GPU",
+                "config2": f"BASELINE config 2: 150 bp single-end, 3' adapter AGATCGGAAGAGC e=0.1, {args.steps} steps x {n} reads",
+                "config4": "BASELINE config 4: 2x150 bp pairs, custom scheme with inline barcode + 8 nt UMI + dual adapters, "
+                           f"--ensure-inline-barcode, {args.steps} steps x {n} resident pairs per GPU",
+            }[args.workload],
             "pairs_per_step_per_gpu": n,
             "read_len": READ_LEN,
-            "scheme": "TAKARAV3" if paired else "-a AGATCGGAAGAGC",
+            "scheme": {"config3": "TAKARAV3", "config2": "-a AGATCGGAAGAGC", "config4": CONFIG4_SCHEME}[args.workload],
             "prefilter": not args.no_filter,
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
@@ -197,12 +222,24 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
             "traffic": traffic,
-            "kernel": "csdev::trim_kernel",
+            "traffic_source": traffic_source,
+            "kernel": "csdev::trim_kernel<.., MODE_SCAN> + <.., MODE_RESOLVE> (one launch of each per step)",
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
+            "kernel_ms_last_step": {"scan": round(split_ms[0], 4), "resolve": round(split_ms[1], 4)},
             "bytes_per_unit": bytes_per_unit,
         },
         "exact_dp_fraction": round((st1.n_exact_dp + st2.n_exact_dp) / max(1, st1.n_reads + st2.n_reads), 4),
     }
+    if valu_insts:
+        # the bound that governs: VALU issue slots.  achieved / peak in wave-instructions per second.
+        peak = N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_INSTR
+        ach = valu_insts / avg_kernel_s
+        result["roofline_valu"] = {
+            "bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
+            "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
+            "valu_insts_per_launch": valu_insts, "cycles_per_instr": VALU_CYCLES_PER_INSTR,
+            "source": traffic_source,
+        }
 
     if rank == 0 and world == 1 and not args.no_copy_probe:
         # measured HBM copy bandwidth of this box: a second denominator next to the 8 TB/s spec

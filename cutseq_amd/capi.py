@@ -16,7 +16,7 @@ LIB_PATH = Path(__file__).with_name("libcutseq_hip.so")
 EXPORTS = (
     "cs_abi_version", "cs_last_error", "cs_device_count", "cs_plan_create", "cs_plan_destroy",
     "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_batch", "cs_sync",
-    "cs_stats_fetch", "cs_last_kernel_ms", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
+    "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
     "cs_free_device", "cs_copy_to_device", "cs_copy_to_host",
 )
 
@@ -71,6 +71,8 @@ def load() -> C.CDLL:
     L.cs_stats_fetch.argtypes = [vp, C.POINTER(abi.cs_stats * 2), i32]
     L.cs_last_kernel_ms.restype = i32
     L.cs_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.cs_last_kernel_split_ms.restype = i32
+    L.cs_last_kernel_split_ms.argtypes = [vp, C.POINTER(C.c_float * 2)]
     L.cs_alloc_pinned.restype = vp
     L.cs_alloc_pinned.argtypes = [C.c_size_t]
     L.cs_free_pinned.restype = None

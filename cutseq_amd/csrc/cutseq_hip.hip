@@ -84,7 +84,7 @@ struct cs_engine {
   int plan_slot = -1;  // index into the device's __constant__ plan table
   unsigned long long *d_stats = nullptr;
   uint32_t *d_tile_counter = nullptr;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;
   bool timed = false;
   uint32_t max_reads = 0, max_stride = 0;
   bool paired = false;
@@ -304,6 +304,7 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
                             g[mode].lds_bytes, stream));
     HIP_TRY(hipGetLastError());
+    if (time_it && mode == csdev::MODE_SCAN) HIP_TRY(hipEventRecord(eng->ev_mid, stream));
   }
   if (time_it) {
     HIP_TRY(hipEventRecord(eng->ev_stop, stream));
@@ -392,6 +393,7 @@ void cs_engine_destroy(cs_engine *eng) {
   for (int m = 0; m < 2; ++m)
     if (eng->d_defer[m]) (void)hipFree(eng->d_defer[m]);
   if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
+  if (eng->ev_mid) (void)hipEventDestroy(eng->ev_mid);
   if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
   delete eng;
@@ -450,6 +452,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   ENG_TRY(hipSetDevice(device));
   ENG_TRY(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
   ENG_TRY(hipEventCreate(&eng->ev_start));
+  ENG_TRY(hipEventCreate(&eng->ev_mid));
   ENG_TRY(hipEventCreate(&eng->ev_stop));
   eng->plan_slot = acquire_plan_slot(device);
   if (eng->plan_slot < 0) {
@@ -577,6 +580,16 @@ int cs_last_kernel_ms(cs_engine *eng, float *ms) {
   HIP_TRY(hipSetDevice(eng->device));
   HIP_TRY(hipEventSynchronize(eng->ev_stop));
   HIP_TRY(hipEventElapsedTime(ms, eng->ev_start, eng->ev_stop));
+  return CS_OK;
+}
+
+int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]) {
+  if (!eng || !ms) return fail(CS_ERR_ARG, "null argument");
+  if (!eng->timed) return fail(CS_ERR_STATE, "no timed launch yet");
+  HIP_TRY(hipSetDevice(eng->device));
+  HIP_TRY(hipEventSynchronize(eng->ev_stop));
+  HIP_TRY(hipEventElapsedTime(&ms[0], eng->ev_start, eng->ev_mid));
+  HIP_TRY(hipEventElapsedTime(&ms[1], eng->ev_mid, eng->ev_stop));
   return CS_OK;
 }
 

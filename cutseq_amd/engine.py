@@ -125,6 +125,12 @@ class TrimEngine:
         capi.check(self.L.cs_last_kernel_ms(self._eng_h, C.byref(ms)))
         return float(ms.value)
 
+    def last_kernel_split_ms(self) -> Tuple[float, float]:
+        """(scan kernel, resolve kernel) of the last ``trim_device`` launch, ms."""
+        ms = (C.c_float * 2)()
+        capi.check(self.L.cs_last_kernel_split_ms(self._eng_h, C.byref(ms)))
+        return float(ms[0]), float(ms[1])
+
     def stats(self, reset: bool = False) -> Tuple[abi.cs_stats, abi.cs_stats]:
         st = (abi.cs_stats * 2)()
         capi.check(self.L.cs_stats_fetch(self._eng_h, C.byref(st), 1 if reset else 0))

@@ -186,8 +186,10 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
                      uint32_t max_stride, cs_engine **out);
 void cs_engine_destroy(cs_engine *eng);
 
-/* The hot path, inputs already resident in HBM: ONE fused kernel launch over both mates
- * (replaces the per-read modifier loop inside runner.run(pipeline, ...), run.py:473,794).
+/* The hot path, inputs already resident in HBM: two kernel launches over both mates -- the scan kernel
+ * (staging, bit-parallel filters, closed forms, cuts, quality trimming; reads that need the exact DP go
+ * to a queue in HBM) and the resolve kernel (strip DP on that queue, then the rest of those reads'
+ * chains) -- replacing the per-read modifier loop inside runner.run(pipeline, ...), run.py:473,794.
  * `stream` is a hipStream_t (NULL = the engine's own stream); asynchronous.
  * r2 == NULL for single-end.  An engine's launches must be ordered with respect to each other
  * (one stream at a time, or event dependencies between streams): they share the engine's tile
@@ -208,8 +210,10 @@ int cs_sync(cs_engine *eng, uint32_t slot);
 int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset);
 
 /* Timing of the last cs_trim_device launch on its stream, measured with HIP events
- * recorded around the kernel (ms).  Synchronises on the stop event. */
+ * recorded around the two kernels (ms).  Synchronises on the stop event. */
 int cs_last_kernel_ms(cs_engine *eng, float *ms);
+/* the same launch split into its two kernels: ms[0] = scan kernel, ms[1] = resolve kernel */
+int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]);
 
 void *cs_alloc_pinned(size_t bytes);
 void cs_free_pinned(void *p);
