@@ -110,6 +110,12 @@ def minimal_report(tp: TrimPlan, totals: dict) -> str:
     return "\t".join(fields) + "\n" + "\t".join(str(v) for v in vals)
 
 
+def error_lengths(op: AdapterOp) -> list:
+    """cutadapt ``ErrorRanges.lengths()``: for 1, 2, ... allowed errors the longest match that still allows one
+    error fewer -- a function of adapter length and error rate only (rate 0.2, 20 nt: [4, 9, 14, 19])."""
+    return [int(errors / op.max_error_rate) - 1 for errors in range(1, int(op.max_error_rate * op.m) + 1)]
+
+
 def _adapter_json(op: AdapterOp, name: str, matches: int) -> dict:
     end, type_name = ADAPTER_TYPES[op.kind_name]
     side = {
@@ -117,8 +123,10 @@ def _adapter_json(op: AdapterOp, name: str, matches: int) -> dict:
         "sequence": op.sequence,
         "error_rate": op.max_error_rate,
         "indels": True,
-        "error_lengths": None,  # per-error-count histograms are not collected on the device
+        "error_lengths": error_lengths(op),
         "matches": matches,
+        # cutadapt reports the bases in front of the adapter for 3' ends only; the one adapter the reference's
+        # report ever describes per mate is the 5' one (first AdapterCutter, run.py:59-73)
         "adjacent_bases": None,
         "dominant_adjacent_base": None,
         "trimmed_lengths": [],  # the reference empties these lists itself (run.py:286-300)
@@ -141,7 +149,9 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
     q1, q2 = _mate_sum(totals, 0, "qualtrim_bp"), (_mate_sum(totals, 1, "qualtrim_bp") if paired else None)
     d = {
         "tag": "Cutadapt report",
-        "cutadapt_version": None,  # no cutadapt in this engine
+        "schema_version": [0, 3],
+        # the report layout is cutadapt 5's; the numbers come from this engine (local version label says so)
+        "cutadapt_version": f"5.0+cutseq.amd.{__version__}",
         "engine": {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
                    "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
                    "per_device": totals["stats"]},

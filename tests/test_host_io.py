@@ -238,6 +238,24 @@ def test_reports_from_oracle_results():
     (a,) = rep["adapters_read1"]
     assert a["five_prime_end"]["sequence"] == op1.sequence and a["three_prime_end"] is None
     assert a["five_prime_end"]["trimmed_lengths"] == []
+    # cutadapt's ErrorRanges for a 20-nt adapter at rate 0.2: one error from 5 nt, two from 10, ... (guide: "error tolerance")
+    assert a["five_prime_end"]["error_lengths"] == [4, 9, 14, 19]
+    assert rep["schema_version"] == [0, 3] and rep["cutadapt_version"].startswith("5.0+")
+
+    def no_none_under(node, path=""):
+        """every None left in the report is one cutadapt itself writes for an unused feature"""
+        allowed = ("filtered.", "reverse_complemented", "poly_a_trimmed", "on_reverse_complement", "three_prime_end",
+                   "adjacent_bases", "dominant_adjacent_base", "untrimmed", "is_untrimmed_any")
+        if isinstance(node, dict):
+            for k, v in node.items():
+                no_none_under(v, f"{path}.{k}")
+        elif isinstance(node, list):
+            for v in node:
+                no_none_under(v, path)
+        else:
+            assert node is not None or any(a in path for a in allowed), path
+
+    no_none_under(rep)
 
 
 # ---------------------------------------------------------------- threaded reader / worker finisher
