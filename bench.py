@@ -42,7 +42,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from cutseq_amd import abi, plan as planmod, synth  # noqa: E402
+from cutseq_amd import abi, plan as planmod, shard, synth  # noqa: E402
 from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig  # noqa: E402
 from cutseq_amd.engine import TrimEngine  # noqa: E402
 
@@ -114,13 +114,15 @@ def main():
     paired = args.workload != "config2"
     tp = make_plan(args.workload, not args.no_filter)
     n = args.pairs
-    # every rank trims its own shard of the read stream: global indices rank*n .. rank*n+n
+    # every rank trims its own shard of the read stream (weak scaling: world * n reads in all), no exchange step
+    first, last = shard.shard_bounds(world * n, rank, world)
+    assert last - first == n
     if args.workload == "config4":
-        batch = synth.generate_pairs(n, READ_LEN, CONFIG4_SCHEME, first_index=rank * n)
+        batch = synth.generate_pairs(n, READ_LEN, CONFIG4_SCHEME, first_index=first)
     elif paired:
-        batch = synth.generate_pairs(n, READ_LEN, first_index=rank * n)
+        batch = synth.generate_pairs(n, READ_LEN, first_index=first)
     else:
-        batch = synth.generate_single_adapter(n, READ_LEN, first_index=rank * n)
+        batch = synth.generate_single_adapter(n, READ_LEN, first_index=first)
     stride = batch.stride
 
     def up(a):

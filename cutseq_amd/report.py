@@ -76,15 +76,6 @@ def first_adapter(chain: Optional[MateChain]):
     return None, None
 
 
-def add_stats(a: dict, b: dict) -> dict:
-    """Sum of two ``cs_stats.as_dict()`` blocks (one device's counters over several engines)."""
-    out = {}
-    for key, va in a.items():
-        vb = b[key]
-        out[key] = [x + y for x, y in zip(va, vb)] if isinstance(va, list) else va + vb
-    return out
-
-
 def _mate_sum(totals: dict, mate: int, field: str) -> int:
     """``totals["stats"]``: one [mate 1, mate 2] pair of ``cs_stats.as_dict()`` blocks per device worker."""
     return sum(int(pair[mate][field]) for pair in totals["stats"])

@@ -22,7 +22,7 @@ import time
 from collections import deque
 from typing import List, Optional
 
-from . import __version__, abi, report
+from . import __version__, abi, report, shard
 from .common import BUILDIN_ADAPTERS, BarcodeConfig, print_builtin_adapters, remove_fq_suffix
 from .plan import CutadaptConfig, TrimPlan, compile_paired, compile_single
 
@@ -208,7 +208,7 @@ class _DeviceWorker(threading.Thread):
 
     def _collect_stats(self):
         part = [s.as_dict() for s in self.engine.stats()]
-        self.stats = part if self.stats is None else [report.add_stats(a, b) for a, b in zip(self.stats, part)]
+        self.stats = part if self.stats is None else [shard.merge_stats([a, b]) for a, b in zip(self.stats, part)]
 
     def _engine_for(self, stride: int, inflight: deque):
         """The engine, rebuilt with longer rows when a chunk needs them -- after everything the old one still

@@ -188,3 +188,29 @@ def test_cli_read_longer_than_the_tile_is_a_user_error(tmp_path, caplog):
         cli.main([str(p), "-A", "TAKARAV3", "-o", str(tmp_path / "o.fq"), "-s", str(tmp_path / "s.fq")])
     assert exc.value.code == 1
     assert "1536" in caplog.text
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path (one process per GPU, shard by global read index, no data-path collective) with two
+    ranks on GPU 0 and gloo for the barrier (CUTSEQ_BENCH_REHEARSAL=1; RCCL wants one device per rank).  The CPU
+    sample at N = 1 checks the device results against the oracle; here the two-rank run must report twice the
+    work of one rank and a positive rate."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CUTSEQ_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(util.GOLDEN.parents[1] / "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--pairs", "300000"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["value"] > 0
+    assert rep["config"]["parallelism"] == "shard2" and rep["config"]["pairs_per_step_per_gpu"] == 300000
+    assert "cpu_baseline" not in rep  # rank 0 at N = 1 only
