@@ -7,12 +7,14 @@ from __future__ import annotations
 
 import ctypes as C
 
-CS_ABI_VERSION = 2
+CS_ABI_VERSION = 3
 CS_MAX_ADAPTER = 128
 CS_MAX_OPS = 24
 CS_MAX_STRIDE = 1536
 
-CS_OP_ADAPTER, CS_OP_CUT, CS_OP_QTRIM = 1, 2, 3
+CS_OP_ADAPTER, CS_OP_CUT, CS_OP_QTRIM, CS_OP_DEMUX = 1, 2, 3, 4
+CS_DEMUX_NONE = 0xFF
+CS_DEMUX_MAX_PREFIX = 11
 
 CS_REF_START, CS_QUERY_START, CS_REF_END, CS_QUERY_STOP = 1, 2, 4, 8
 CS_WHERE_BACK = 14
@@ -36,6 +38,7 @@ CS_F_POLY = 0x08
 CS_F_QTRIMMED = 0x10
 CS_F_TOO_SHORT = 0x20
 CS_F_UNTRIMMED = 0x40
+CS_F_AMBIGUOUS = 0x80
 
 CS_OK = 0
 CS_ERR_ARG, CS_ERR_HIP, CS_ERR_NO_GPU, CS_ERR_NOMEM, CS_ERR_STATE = -1, -2, -3, -4, -5
@@ -120,6 +123,7 @@ class cs_reads(C.Structure):
         ("len", C.c_void_p),
         ("out", C.c_void_p),
         ("cap2", C.c_void_p),
+        ("bc", C.c_void_p),
     ]
 
 

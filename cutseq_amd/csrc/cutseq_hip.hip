@@ -46,6 +46,7 @@ struct Slot {
   uint16_t *d_len[2] = {nullptr, nullptr};
   cs_result *d_out[2] = {nullptr, nullptr};
   cs_cap2 *d_cap2 = nullptr;
+  uint8_t *d_bc[2] = {nullptr, nullptr};
   hipEvent_t done = nullptr;
   bool busy = false;
 };
@@ -54,6 +55,7 @@ struct Slot {
 
 struct cs_plan {
   csdev::DevPlan host;
+  std::vector<uint16_t> demux[2][CS_MAX_OPS];  // look-up tables of the CS_OP_DEMUX ops
 };
 
 #include <mutex>
@@ -97,6 +99,7 @@ struct cs_engine {
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds[2] = {0, 0};
   void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
+  std::vector<void *> d_tables;           // device copies of the CS_OP_DEMUX tables
   uint32_t defer_capacity = 0;            // records per mate
   // tuning knobs, read once from the environment when the engine is created
   uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 0;
@@ -170,6 +173,11 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
       break;
     case CS_OP_QTRIM:
       break;
+    case CS_OP_DEMUX:
+      if (op.m < 1 || op.k > op.m || op.m + op.k > CS_DEMUX_MAX_PREFIX)
+        return fail(CS_ERR_ARG, "mate %d op %d: demux barcode length %u with %u errors (m + k <= %d)", mate, index, op.m,
+                    op.k, CS_DEMUX_MAX_PREFIX);
+      break;
     default:
       return fail(CS_ERR_ARG, "mate %d op %d: unknown op kind %u", mate, index, op.kind);
   }
@@ -238,6 +246,7 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     a.mate[m].len = rr[m]->len;
     a.mate[m].out = rr[m]->out;
     a.mate[m].cap2 = rr[m]->cap2;
+    a.mate[m].bc = rr[m]->bc;
   }
   // queue of deferred reads: a read is deferred at most once by the scan kernel, so n_reads records per
   // mate always suffice (32 bytes each; typically a few per cent are used)
@@ -374,6 +383,23 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
 
 void cs_plan_destroy(cs_plan *plan) { delete plan; }
 
+int cs_plan_set_demux(cs_plan *plan, int mate, int op_index, const uint16_t *table, size_t entries) {
+  if (!plan || !table) return fail(CS_ERR_ARG, "null plan or table");
+  if (mate < 1 || mate > 2 || op_index < 0 || op_index >= plan->host.n_ops[mate - 1])
+    return fail(CS_ERR_ARG, "mate %d op %d: no such op", mate, op_index);
+  const cs_op &op = plan->host.ops[mate - 1][op_index].op;
+  if (op.kind != CS_OP_DEMUX) return fail(CS_ERR_ARG, "mate %d op %d is not a CS_OP_DEMUX op", mate, op_index);
+  size_t want = 0, pw = 1;
+  for (int l = 0; l <= op.m + op.k; ++l, pw *= 5) want += pw;
+  if (entries != want) return fail(CS_ERR_ARG, "demux table: %zu entries, expected %zu for m + k = %d", entries, want, op.m + op.k);
+  try {
+    plan->demux[mate - 1][op_index].assign(table, table + entries);
+  } catch (const std::bad_alloc &) {
+    return fail(CS_ERR_NOMEM, "out of memory");
+  }
+  return CS_OK;
+}
+
 void cs_engine_destroy(cs_engine *eng) {
   if (!eng) return;
   if (eng->device >= 0) (void)hipSetDevice(eng->device);
@@ -383,6 +409,7 @@ void cs_engine_destroy(cs_engine *eng) {
       if (s.d_qual[m]) (void)hipFree(s.d_qual[m]);
       if (s.d_len[m]) (void)hipFree(s.d_len[m]);
       if (s.d_out[m]) (void)hipFree(s.d_out[m]);
+      if (s.d_bc[m]) (void)hipFree(s.d_bc[m]);
     }
     if (s.d_cap2) (void)hipFree(s.d_cap2);
     if (s.done) (void)hipEventDestroy(s.done);
@@ -392,6 +419,7 @@ void cs_engine_destroy(cs_engine *eng) {
   if (eng->d_tile_counter) (void)hipFree(eng->d_tile_counter);
   for (int m = 0; m < 2; ++m)
     if (eng->d_defer[m]) (void)hipFree(eng->d_defer[m]);
+  for (void *t : eng->d_tables) (void)hipFree(t);
   if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
   if (eng->ev_mid) (void)hipEventDestroy(eng->ev_mid);
   if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
@@ -460,8 +488,28 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     cs_engine_destroy(eng);
     return CS_ERR_STATE;
   }
-  ENG_TRY(hipMemcpyToSymbol(HIP_SYMBOL(csdev::c_plans), &plan->host, sizeof(csdev::DevPlan),
-                            (size_t)eng->plan_slot * sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
+  {
+    // the device copy of the plan carries this device's addresses of the demux tables
+    csdev::DevPlan dp = plan->host;
+    for (int mt = 0; mt < 2; ++mt)
+      for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
+        if (dp.ops[mt][i].op.kind != CS_OP_DEMUX) continue;
+        const std::vector<uint16_t> &tab = plan->demux[mt][i];
+        if (tab.empty()) {
+          fail(CS_ERR_STATE, "mate %d op %d: CS_OP_DEMUX without a table (cs_plan_set_demux)", mt + 1, i);
+          cs_engine_destroy(eng);
+          return CS_ERR_STATE;
+        }
+        void *d = nullptr;
+        ENG_TRY(hipMalloc(&d, tab.size() * sizeof(uint16_t)));
+        eng->d_tables.push_back(d);
+        ENG_TRY(hipMemcpy(d, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        dp.ops[mt][i].peq[0] = (uint64_t)(uintptr_t)d;
+        dp.ops[mt][i].peq[1] = (uint64_t)tab.size();
+      }
+    ENG_TRY(hipMemcpyToSymbol(HIP_SYMBOL(csdev::c_plans), &dp, sizeof(csdev::DevPlan),
+                              (size_t)eng->plan_slot * sizeof(csdev::DevPlan), hipMemcpyHostToDevice));
+  }
   ENG_TRY(hipMalloc(&eng->d_stats, 2 * sizeof(cs_stats)));
   ENG_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
   ENG_TRY(hipMalloc(&eng->d_tile_counter, kTileCounterBytes));
@@ -473,6 +521,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
       ENG_TRY(hipMalloc(&s.d_qual[m], bytes));
       ENG_TRY(hipMalloc(&s.d_len[m], (size_t)max_reads * sizeof(uint16_t)));
       ENG_TRY(hipMalloc(&s.d_out[m], (size_t)max_reads * sizeof(cs_result)));
+      ENG_TRY(hipMalloc(&s.d_bc[m], (size_t)max_reads));
     }
     ENG_TRY(hipMalloc(&s.d_cap2, (size_t)max_reads * sizeof(cs_cap2)));
     ENG_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
@@ -540,6 +589,7 @@ int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_re
     dev[m].len = s.d_len[m];
     dev[m].out = s.d_out[m];
     dev[m].cap2 = (m == 0 && rr[m]->cap2) ? s.d_cap2 : nullptr;
+    dev[m].bc = rr[m]->bc ? s.d_bc[m] : nullptr;
   }
   int rc = launch(eng, eng->stream, &dev[0], r2 ? &dev[1] : nullptr, n_reads, stride, false);
   if (rc) return rc;
@@ -547,6 +597,7 @@ int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_re
     HIP_TRY(hipMemcpyAsync(rr[m]->out, s.d_out[m], (size_t)n_reads * sizeof(cs_result), hipMemcpyDeviceToHost, eng->stream));
     if (m == 0 && rr[m]->cap2)
       HIP_TRY(hipMemcpyAsync(rr[m]->cap2, s.d_cap2, (size_t)n_reads * sizeof(cs_cap2), hipMemcpyDeviceToHost, eng->stream));
+    if (rr[m]->bc) HIP_TRY(hipMemcpyAsync(rr[m]->bc, s.d_bc[m], (size_t)n_reads, hipMemcpyDeviceToHost, eng->stream));
   }
   HIP_TRY(hipEventRecord(s.done, eng->stream));
   s.busy = true;

@@ -1,0 +1,111 @@
+"""Look-up tables for the demultiplexing op (``CS_OP_DEMUX``, include/cutseq_hip.h) -- an extension, the
+reference has no demultiplexer (BASELINE.json config 5).
+
+The op stands for one ``AdapterCutter([PrefixAdapter(barcode, rate)])`` per barcode.  Whether such an
+adapter matches, and how many bases it removes, depends on nothing but the first ``m + k`` bases of the
+read (``Aligner.locate`` stops at column ``m + k`` without a free query start).  So the table is built by
+RUNNING those adapter ops -- the device's own, through the C ABI -- on every possible prefix of every
+length 0 .. m + k over the alphabet {A, C, T, G, other}, one single-op plan per barcode, and merging the
+outcomes: "equal to B independent ``--ensure-inline-barcode`` runs" holds by construction.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi
+from .plan import DemuxOp, MateChain, TrimPlan, prefix
+
+DIGITS = b"ACTGN"  # digit d of the base-5 index = bits 2:1 of the ASCII code for A, C, T, G; 4 = anything else
+
+
+def table_entries(span: int) -> int:
+    return (5 ** (span + 1) - 1) // 4
+
+
+def all_prefixes(span: int):
+    """Every string over DIGITS of length 0 .. span as rows of a read batch, in table order
+    -> (seq[n, stride] u8, len[n] u16)."""
+    n = table_entries(span)
+    stride = max(4, (span + 3) // 4 * 4)
+    seq = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    letters = np.frombuffer(DIGITS, dtype=np.uint8)
+    start = 0
+    for length in range(span + 1):
+        count = 5 ** length
+        idx = np.arange(count, dtype=np.int64)
+        for t in range(length):
+            seq[start:start + count, t] = letters[(idx // 5 ** t) % 5]
+        lens[start:start + count] = length
+        start += count
+    return seq, lens
+
+
+def build_table(op: DemuxOp, device: int = 0, select_rule: int = abi.CS_SELECT_LEFTMOST,
+                indel_tie: int = abi.CS_TIE_INSERTION) -> np.ndarray:
+    """The table of ``op`` (uint16, ``table_entries(m + k)`` entries), computed on ``device``."""
+    from .engine import TrimEngine
+
+    span = op.m + op.k
+    seq, lens = all_prefixes(span)
+    qual = np.full_like(seq, ord("I"))
+    n = len(lens)
+    best = np.full(n, abi.CS_DEMUX_NONE, dtype=np.uint16)
+    rstop = np.zeros(n, dtype=np.uint16)
+    hits = np.zeros(n, dtype=np.uint16)
+    exact_taken = np.zeros(n, dtype=bool)
+    for index, code in enumerate(op.barcodes):
+        one = TrimPlan(r1=MateChain([prefix(code, op.max_error_rate, abi.CS_F_INLINE)]), r2=None, has_umi=False,
+                       min_length=0, untrimmed_filter=False, select_rule=select_rule, indel_tie=indel_tie)
+        with TrimEngine(one, device=device, slots=1, max_reads=n, max_stride=seq.shape[1]) as eng:
+            res, _, _ = eng.trim(seq, qual, lens)
+        matched = (res["flags"] & abi.CS_F_INLINE) != 0
+        # an exact copy of the barcode at the start beats an inexact match of another one; else the lowest index
+        m = op.m
+        exact = matched & (lens >= m) & (res["start"] == m) & (seq[:, :m] == np.frombuffer(code.encode(), np.uint8)).all(axis=1)
+        take = matched & ((best == abi.CS_DEMUX_NONE) | (exact & ~exact_taken))
+        best[take] = index
+        rstop[take] = res["start"][take]
+        exact_taken |= exact
+        hits += matched
+    table = best | (rstop << 8) | ((hits > 1).astype(np.uint16) << 14)
+    return np.ascontiguousarray(table, dtype=np.uint16)
+
+
+def ensure_tables(plan: TrimPlan, device: int = 0) -> None:
+    """Build the tables the plan's demultiplexing ops still lack."""
+    for _mate, _i, op in plan.demux_ops():
+        if op.table is None:
+            op.table = build_table(op, device, plan.select_rule, plan.indel_tie)
+
+
+def ambiguous_prefixes(op: DemuxOp) -> int:
+    """How many full-length prefixes (m + k bases of A/C/G/T only) more than one barcode claims."""
+    span = op.m + op.k
+    start = table_entries(span - 1)
+    block = op.table[start:]
+    idx = np.arange(len(block), dtype=np.int64)
+    acgt = np.ones(len(block), dtype=bool)
+    for t in range(span):
+        acgt &= (idx // 5 ** t) % 5 != 4
+    return int(((block & 0x4000) != 0)[acgt].sum())
+
+
+def read_barcode_file(path: str):
+    """``name<TAB>sequence`` (or ``sequence`` alone) per line, ``#`` comments -> ([names], [sequences])."""
+    names, codes = [], []
+    with open(path) as fh:
+        for line in fh:
+            line = line.split("#", 1)[0].strip()
+            if not line:
+                continue
+            fields = line.replace(",", "\t").split()
+            if len(fields) == 1:
+                names.append(fields[0].upper())
+                codes.append(fields[0].upper())
+            else:
+                names.append(fields[0])
+                codes.append(fields[1].upper())
+    if len(set(names)) != len(names):
+        raise ValueError(f"{path}: duplicate barcode name")
+    return names, codes

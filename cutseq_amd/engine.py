@@ -24,11 +24,16 @@ class TrimEngine:
         self.device = device
         self._plan_h = C.c_void_p()
         self._eng_h = C.c_void_p()
+        if any(True for _ in plan.demux_ops()):
+            from . import demux  # tables of the demultiplexing ops: built on this device when still missing
+            demux.ensure_tables(plan, device)
         a1, n1, a2, n2 = plan.pack()
         params = plan.params()
         capi.check(self.L.cs_plan_create(C.cast(a1, C.c_void_p), n1,
                                          C.cast(a2, C.c_void_p) if a2 is not None else None, n2,
                                          C.byref(params), C.byref(self._plan_h)))
+        for mate, index, op in plan.demux_ops():
+            capi.check(self.L.cs_plan_set_demux(self._plan_h, mate, index, op.table.ctypes.data, op.table.size))
         self.n_slots, self.max_reads, self.max_stride = slots, max_reads, max_stride
         try:
             capi.check(self.L.cs_engine_create(self._plan_h, device, slots, max_reads, max_stride,
@@ -78,9 +83,10 @@ class TrimEngine:
         if n and int(lens.max()) > stride:
             raise ValueError(f"len{name}: a read is longer than the row stride {stride}")
 
-    def submit(self, slot: int, seq1, qual1, len1, seq2=None, qual2=None, len2=None, out=None):
+    def submit(self, slot: int, seq1, qual1, len1, seq2=None, qual2=None, len2=None, out=None, bc=None):
         """Asynchronous: returns the (still being filled) result arrays; call ``wait(slot)``.
-        ``out``: optional (res1, cap2 | None, res2 | None) arrays to fill (e.g. pinned memory)."""
+        ``out``: optional (res1, cap2 | None, res2 | None) arrays to fill (e.g. pinned memory).
+        ``bc``: optional uint8 array [n] for the barcode index of mate 1 (plans with a demultiplexing op)."""
         if seq1.ndim != 2:
             raise ValueError("seq1: expected a 2-D array [n_reads, stride]")
         n, stride = seq1.shape
@@ -98,6 +104,10 @@ class TrimEngine:
             cap2 = np.empty(n, dtype=abi.CAP2_DTYPE) if self.plan.needs_cap2 else None
             out2 = np.empty(n, dtype=abi.RESULT_DTYPE) if seq2 is not None else None
         r1 = self._reads(seq1, qual1, len1, out1, cap2)
+        if bc is not None:
+            if bc.dtype != np.uint8 or bc.shape != (n,) or not bc.flags.c_contiguous:
+                raise ValueError(f"bc: expected a C-contiguous uint8 array of shape ({n},)")
+            r1.bc = bc.ctypes.data
         r2p = None
         if seq2 is not None:
             r2 = self._reads(seq2, qual2, len2, out2)

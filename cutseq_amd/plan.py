@@ -45,6 +45,8 @@ class CutadaptConfig:
         self.shortcut = abi.CS_SHORTCUT_NONE       # cutadapt >= 3: no str.find before the aligner
         self.case_rule = abi.CS_CASE_FOLD          # match_to aligns sequence.upper()
         self.indel_tie = abi.CS_TIE_INSERTION      # SURVEY appendix B.2 order
+        # extension (BASELINE.json config 5): demultiplex on these inline barcodes (replaces the scheme's inline5)
+        self.demux_barcodes = None
 
 
 @dataclass
@@ -126,7 +128,46 @@ class QTrimOp:
         return f"QualityTrimmer(cutoff_front=0, cutoff_back={self.cutoff_back}, base={self.base})"
 
 
-Op = Union[AdapterOp, CutOp, QTrimOp]
+@dataclass
+class DemuxOp:
+    """Extension (BASELINE.json config 5): one pass over ``barcodes`` where the reference would run
+    ``AdapterCutter([PrefixAdapter(barcode, max_error_rate)])`` once per barcode with
+    ``--ensure-inline-barcode`` (cutseq/run.py:357-362, 592-597).  ``table`` is the look-up table of
+    ``include/cutseq_hip.h`` (CS_OP_DEMUX); :mod:`cutseq_amd.demux` builds it on the device."""
+
+    barcodes: Sequence[str]
+    max_error_rate: float
+    match_flag: int = 0
+    required: bool = True
+    table: Optional[object] = None  # numpy uint16 array once built
+
+    def __post_init__(self):
+        self.barcodes = [b.upper().replace("U", "T") for b in self.barcodes]
+        if not self.barcodes or len(self.barcodes) > 255:
+            raise ValueError("between 1 and 255 barcodes, please")
+        if len({len(b) for b in self.barcodes}) != 1 or not self.barcodes[0]:
+            raise ValueError("demultiplexing needs barcodes of one common, non-zero length")
+        if len(set(self.barcodes)) != len(self.barcodes):
+            raise ValueError("duplicate barcode")
+        if any(set(b) - set("ACGT") for b in self.barcodes):
+            raise ValueError("barcodes must consist of A, C, G, T")
+        if self.m + self.k > abi.CS_DEMUX_MAX_PREFIX:
+            raise ValueError(f"barcode length + allowed errors must not exceed {abi.CS_DEMUX_MAX_PREFIX}")
+
+    @property
+    def m(self) -> int:
+        return len(self.barcodes[0])
+
+    @property
+    def k(self) -> int:
+        return int(self.max_error_rate * self.m)
+
+    def __repr__(self):
+        return (f"Demultiplexer({len(self.barcodes)} x PrefixAdapter(length={self.m}, "
+                f"max_error_rate={self.max_error_rate}))")
+
+
+Op = Union[AdapterOp, CutOp, QTrimOp, DemuxOp]
 
 
 @dataclass
@@ -162,6 +203,20 @@ class TrimPlan:
     @property
     def needs_cap2(self) -> bool:
         return any(isinstance(o, CutOp) and o.capture == 2 for o in self.r1.ops)
+
+    @property
+    def demux(self) -> Optional[DemuxOp]:
+        """The demultiplexing op of mate 1, if the plan has one."""
+        return next((o for o in self.r1.ops if isinstance(o, DemuxOp)), None)
+
+    def demux_ops(self):
+        """(mate, op index, op) of every demultiplexing op."""
+        for mate, chain in ((1, self.r1), (2, self.r2)):
+            if chain is None:
+                continue
+            for i, o in enumerate(chain.ops):
+                if isinstance(o, DemuxOp):
+                    yield mate, i, o
 
     def params(self) -> abi.cs_params:
         p = abi.cs_params()
@@ -211,6 +266,11 @@ def pack_ops(ops: Sequence[Op]):
             c.conditional = 1 if op.conditional else 0
             c.force_min_len = max(0, min(int(op.force_min_len), 0xFFFF))
             c.capture = op.capture
+        elif isinstance(op, DemuxOp):
+            c.kind = abi.CS_OP_DEMUX
+            c.m, c.k = op.m, op.k
+            c.match_flag = op.match_flag
+            c.required = 1 if op.required else 0
         elif isinstance(op, QTrimOp):
             c.kind = abi.CS_OP_QTRIM
             c.q_cutoff = max(-0x8000, min(int(op.cutoff_back), 0x7FFF))
@@ -262,6 +322,18 @@ def _poly_t():
     return non_internal_front("T" * POLY_LENGTH, POLY_MAX_ERRORS, abi.CS_F_POLY)
 
 
+def _demux_op(barcode: BarcodeConfig, settings) -> Optional[DemuxOp]:
+    codes = getattr(settings, "demux_barcodes", None)
+    if not codes:
+        return None
+    if barcode.inline5.len == 0:
+        raise ValueError("demultiplexing needs a scheme with a 5' inline barcode, e.g. P5(ATCACG)NNNN>P7")
+    op = DemuxOp(list(codes), MAX_ERRORS, abi.CS_F_INLINE, required=True)
+    if op.m != barcode.inline5.len:
+        raise ValueError(f"the barcodes are {op.m} nt long, the scheme's inline barcode {barcode.inline5.len}")
+    return op
+
+
 def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_requested: bool = False) -> TrimPlan:
     """Single-end chain, step for step as cutseq/run.py:326-426."""
     untrimmed_filter = (
@@ -273,7 +345,11 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     ops.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5, sc))
     ops.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4: inline barcodes
-    if barcode.inline5.len > 0:
+    demux = _demux_op(barcode, settings)
+    if demux is not None:
+        untrimmed_filter = True  # a read without any of the barcodes goes where --ensure-inline-barcode sends it
+        ops.append(demux)
+    elif barcode.inline5.len > 0:
         ops.append(prefix(barcode.inline5.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
     if barcode.inline3.len > 0:
         ops.append(suffix(barcode.inline3.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
@@ -339,7 +415,12 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     o1.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     o2.append(back(barcode.p5.rc, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4
-    if barcode.inline5.len > 0:
+    demux = _demux_op(barcode, settings)
+    if demux is not None:
+        untrimmed_filter = True
+        o1.append(demux)
+        o2.append(CutOp(-barcode.inline5.len))
+    elif barcode.inline5.len > 0:
         o1.append(prefix(barcode.inline5.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
         o2.append(CutOp(-barcode.inline5.len))
     if barcode.inline3.len > 0:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 2
+#define CS_ABI_VERSION 3
 #define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
 #define CS_MAX_OPS 24      /* longest per-mate op chain                           */
 #define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
@@ -43,7 +43,21 @@ typedef enum cs_status {
 
 /* ---- op table: what cutseq/run.py:305-433 (single) and :493-731 (paired) compile -- */
 
-enum { CS_OP_ADAPTER = 1, CS_OP_CUT = 2, CS_OP_QTRIM = 3 };
+enum { CS_OP_ADAPTER = 1, CS_OP_CUT = 2, CS_OP_QTRIM = 3, CS_OP_DEMUX = 4 };
+
+/* CS_OP_DEMUX -- extension, not a reference capability (BASELINE.json config 5): ONE pass
+ * decides which of up to 255 equally long inline barcodes starts the read, where the reference would
+ * need one `--ensure-inline-barcode` run per barcode, each with AdapterCutter([PrefixAdapter(barcode, 0.2)])
+ * (run.py:357-362, 592-597).  A PrefixAdapter match depends on nothing but the first m + k bases of the
+ * interval, so the op is a table look-up: entry = outcome of all those PrefixAdapter ops on that prefix,
+ * built by running them (cutseq_amd/demux.py drives the device's own adapter op over every possible
+ * prefix) and attached with cs_plan_set_demux.  Alphabet {A, C, G, T, other}; prefixes of every length
+ * 0 .. m + k (reads shorter than m + k) are covered.  The matched barcode's index goes to cs_reads.bc. */
+#define CS_DEMUX_NONE 0xFF      /* cs_reads.bc: no barcode matched                                   */
+#define CS_DEMUX_MAX_PREFIX 11  /* m + k <= 11: at most 5^11 + ... table entries (2 bytes each)       */
+/* table entry (uint16): [7:0] barcode index or CS_DEMUX_NONE, [11:8] bases the match removes,
+ * [14] more than one barcode matched (reported: an exact copy if there is one, else the lowest index) */
+#define CS_DEMUX_ENTRY(id, rstop, ambiguous) ((uint16_t)((id) | ((rstop) << 8) | ((ambiguous) ? 0x4000 : 0)))
 
 /* cutadapt aligner flags (cutadapt.align.EndSkip) */
 enum { CS_REF_START = 1, CS_QUERY_START = 2, CS_REF_END = 4, CS_QUERY_STOP = 8 };
@@ -87,7 +101,8 @@ enum {
   CS_F_POLY = 0x08,      /* a poly-A/T adapter matched (run.py:388-413, 673-716)  */
   CS_F_QTRIMMED = 0x10,  /* QualityTrimmer removed >= 1 base                      */
   CS_F_TOO_SHORT = 0x20, /* TooShort(min_length) is true for this mate (run.py:446-451) */
-  CS_F_UNTRIMMED = 0x40  /* IsUntrimmedAny is true for this mate (run.py:97-110)  */
+  CS_F_UNTRIMMED = 0x40, /* IsUntrimmedAny is true for this mate (run.py:97-110)  */
+  CS_F_AMBIGUOUS = 0x80  /* CS_OP_DEMUX: more than one barcode matched this read   */
 };
 
 typedef struct cs_op {
@@ -104,8 +119,8 @@ typedef struct cs_op {
   uint8_t homopolymer;   /* ADAPTER: filled by cs_plan_create (all bases equal)       */
   uint8_t q_base;        /* QTRIM: quality base (33)                                  */
   uint8_t stat_slot;     /* index into cs_stats.op_matched                            */
-  uint16_t m;            /* ADAPTER: sequence length                                  */
-  uint16_t k;            /* ADAPTER: int(max_error_rate * m), computed in double on the host */
+  uint16_t m;            /* ADAPTER: sequence length; DEMUX: barcode length           */
+  uint16_t k;            /* ADAPTER / DEMUX: int(max_error_rate * m), computed in double on the host */
   uint16_t min_overlap;  /* ADAPTER: already capped to m                              */
   int16_t cut_len;       /* CUT: >0 from the 5' end, <0 from the 3' end               */
   uint16_t force_min_len;/* CUT (conditional): force_trim_min_length                  */
@@ -162,6 +177,7 @@ typedef struct cs_reads {
   const uint16_t *len;
   cs_result *out;
   cs_cap2 *cap2; /* may be NULL */
+  uint8_t *bc;   /* may be NULL; CS_OP_DEMUX: index of the barcode that matched, CS_DEMUX_NONE otherwise */
 } cs_reads;
 
 typedef struct cs_plan cs_plan;
@@ -177,6 +193,12 @@ int cs_device_count(void); /* number of visible HIP devices, <0 on error */
 int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, const cs_params *params,
                    cs_plan **out);
 void cs_plan_destroy(cs_plan *plan);
+
+/* Attach the look-up table of a CS_OP_DEMUX op (mate 1 or 2, op index).  `table` holds one uint16 entry per
+ * prefix: first the single entry of the empty prefix, then the 5 prefixes of length 1, ... up to length
+ * m + k, each block indexed by sum(digit[t] * 5^t) with digit = 0, 1, 2, 3 for A, C, T, G (bits 2:1 of the
+ * ASCII code) and 4 for anything else; `entries` must be (5^(m+k+1) - 1) / 4.  The plan copies the table. */
+int cs_plan_set_demux(cs_plan *plan, int mate, int op_index, const uint16_t *table, size_t entries);
 
 /* One engine per GPU (one per process in the multi-GPU layout; replaces
  * make_runner(inpaths, cores=threads), run.py:436,753). Uploads the op tables, owns a

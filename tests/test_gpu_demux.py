@@ -1,0 +1,130 @@
+"""CS_OP_DEMUX (extension, BASELINE.json config 5): one device pass against B independent
+``--ensure-inline-barcode`` runs of the oracle -- the parity definition of SURVEY.md 8 f-4."""
+import random
+
+import numpy as np
+import pytest
+
+from cutseq_amd import abi, demux, plan as planmod, synth
+from cutseq_amd.common import BarcodeConfig
+from cutseq_amd.engine import TrimEngine
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def edit_distance(a: str, b: str) -> int:
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def barcode_set(rng: random.Random, count: int, length: int, min_dist: int):
+    codes = []
+    while len(codes) < count:
+        c = util.random_dna(rng, length)
+        if all(edit_distance(c, o) >= min_dist for o in codes):
+            codes.append(c)
+    return codes
+
+
+def scheme_with(code: str) -> str:
+    return f"ACACGACGCTCTTCCGATCT({code})NNNNNNNN>AGATCGGAAGAGCACACGTC"
+
+
+def plant_barcodes(rng, batch, codes, length):
+    """Overwrite the inline barcode of every R1 with one of `codes` (sometimes damaged, sometimes foreign)."""
+    truth = []
+    for i in range(batch.n):
+        u = rng.random()
+        if u < 0.08:
+            code, which = util.random_dna(rng, length), -1
+        else:
+            which = rng.randrange(len(codes))
+            code = codes[which]
+            if u < 0.3:
+                code = util.mutate(rng, code, 1)
+            elif u < 0.35:
+                code = util.mutate(rng, code, 2)
+        row = batch.seq1[i]
+        tail = bytes(row[length:int(batch.len1[i])])
+        new = (code.encode() + tail)[: int(batch.len1[i])]
+        row[: len(new)] = np.frombuffer(new, dtype=np.uint8)
+        truth.append(which)
+    return truth
+
+
+@pytest.mark.parametrize("paired,length,count", [(True, 8, 24), (False, 6, 12)])
+def test_demux_equals_independent_runs(paired, length, count):
+    rng = random.Random(length * 100 + count)
+    codes = barcode_set(rng, count, length, 4)
+    st = planmod.CutadaptConfig()
+    st.ensure_inline_barcode = True
+    st.trim_polyA = True
+    n = 6000
+    batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=length, single_end=not paired, art5_fraction=0.01)
+    plant_barcodes(rng, batch, codes, length)
+    if paired:  # a few very short mates: prefixes shorter than m + k
+        batch.len1[:40] = np.arange(40, dtype=np.uint16) % 12
+    compile_ = planmod.compile_paired if paired else planmod.compile_single
+
+    st.demux_barcodes = codes
+    tp = compile_(BarcodeConfig(scheme_with(codes[0])), st)
+    assert tp.demux is not None and tp.untrimmed_filter
+    bc = np.empty(n, dtype=np.uint8)
+    with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
+        res = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
+        eng.wait(0)
+        g1, _, g2 = res
+        gst1, _ = eng.stats()
+    amb = (g1["flags"] & abi.CS_F_AMBIGUOUS) != 0  # reads that more than one barcode claims at this error rate
+    assert amb.mean() < 0.01
+
+    # B independent runs of the reference shape: --ensure-inline-barcode with ONE barcode each (CPU oracle)
+    st.demux_barcodes = None
+    runs = []
+    for code in codes:
+        one = compile_(BarcodeConfig(scheme_with(code)), st)
+        (o1, _, _), m2 = util.oracle_run(one, batch, threads=8)
+        runs.append((o1, m2[0] if m2 else None))
+    matched = np.stack([(o1["flags"] & abi.CS_F_INLINE) != 0 for o1, _ in runs])  # [barcode, read]
+    assert np.array_equal(matched.sum(axis=0) > 1, amb)  # the flag marks exactly the reads several runs would claim
+    want_bc = np.where(matched.any(axis=0), matched.argmax(axis=0), abi.CS_DEMUX_NONE).astype(np.uint8)
+    assert np.array_equal(bc[~amb], want_bc[~amb])
+    assert np.all(matched[bc[amb].astype(np.int64), np.nonzero(amb)[0]])  # an ambiguous read goes to one of its claimants
+    assert 0.5 < float((bc != abi.CS_DEMUX_NONE).mean()) < 0.99
+    own = np.where(bc == abi.CS_DEMUX_NONE, 0, bc).astype(np.int64)  # unassigned reads look the same in every run
+    pick = lambda arrs: np.stack(arrs)[own, np.arange(n)]
+    want1 = pick([o1 for o1, _ in runs])
+    want1["flags"] |= np.where(amb, abi.CS_F_AMBIGUOUS, 0).astype(np.uint8)
+    assert np.array_equal(g1, want1)
+    if paired:
+        assert np.array_equal(g2, pick([o2 for _, o2 in runs]))
+    assert int(gst1.op_matched[2]) == int((bc != abi.CS_DEMUX_NONE).sum())  # op 2 of mate 1 is the demultiplexer
+
+
+def test_demux_table_matches_the_oracle_on_every_prefix():
+    """The device-built table against the CPU oracle's PrefixAdapter on all 5^0 + ... + 5^(m+k) prefixes."""
+    rng = random.Random(3)
+    codes = barcode_set(rng, 5, 5, 3)
+    op = planmod.DemuxOp(codes, 0.2, abi.CS_F_INLINE)
+    op.table = demux.build_table(op, 0)
+    seq, lens = demux.all_prefixes(op.m + op.k)
+    batch = util.batch_from_reads([(bytes(seq[i, : lens[i]]).decode(), "I" * int(lens[i])) for i in range(len(lens))])
+    n_match = np.zeros(len(lens), dtype=int)
+    for index, code in enumerate(codes):
+        one = planmod.TrimPlan(r1=planmod.MateChain([planmod.prefix(code, 0.2, abi.CS_F_INLINE)]), r2=None, has_umi=False,
+                               min_length=0, untrimmed_filter=False)
+        (o1, _, _), _ = util.oracle_run(one, batch, threads=8)
+        hit = (o1["flags"] & abi.CS_F_INLINE) != 0
+        n_match += hit
+        mine = (op.table & 0xFF) == index
+        assert np.all(hit[mine])  # whatever the table assigns to this barcode, the oracle matches too ...
+        assert np.array_equal((op.table[mine] >> 8) & 0xF, o1["start"][mine])  # ... and removes as many bases
+    assert np.array_equal((op.table & 0xFF) == abi.CS_DEMUX_NONE, n_match == 0)
+    assert np.array_equal((op.table & 0x4000) != 0, n_match > 1)
