@@ -458,3 +458,115 @@ int64_t csh_format_chunk(const csh_format_params *fp, int64_t n, uint32_t stride
     for (int m = 0; m < 2; m++) out_len[r][m] = w[r][m] - out[r][m];
   return 0;
 }
+
+
+/* ---- demultiplexed output (extension, BASELINE.json config 5): the trimmed route split by barcode -------------
+ * Like csh_format_chunk, but every record of route 0 goes to the bin bin[i] (< n_bins) names: the bins of one
+ * mate lie back to back in out_binned[mate] (capacity as for a route buffer), bin b at
+ * [bin_off[mate * (n_bins + 1) + b], bin_off[.. + b + 1]).  Two passes: sizes, then bytes.  Records whose
+ * bin is out of range (no barcode) are written to route 2 whatever their flags say.
+ * bin_counts[b] receives the records (pairs) of bin b, counts[1], counts[2] those of the other routes. */
+typedef struct {
+  int route;
+  int32_t id1o, id1l, id2o, id2l, nl1, nl2;
+} csh_prep;
+
+static int prep_record(const csh_format_params *fp, int64_t i, const uint8_t *raw1, const int64_t *name_off1,
+                       const int32_t *name_len1, const csh_result *res1, const uint8_t *raw2, const int64_t *name_off2,
+                       const int32_t *name_len2, const csh_result *res2, csh_prep *p) {
+  const uint8_t *nm1 = raw1 + name_off1[i];
+  p->nl1 = strip_suffixes(nm1, name_len1[i], fp->suffix1);
+  read_id(nm1, p->nl1, &p->id1o, &p->id1l);
+  unsigned flags = res1[i].flags;
+  if (fp->paired) {
+    const uint8_t *nm2 = raw2 + name_off2[i];
+    p->nl2 = strip_suffixes(nm2, name_len2[i], fp->suffix2);
+    if (!ids_match(nm1, p->nl1, nm2, p->nl2)) return -1;
+    read_id(nm2, p->nl2, &p->id2o, &p->id2l);
+    flags |= res2[i].flags;
+  }
+  p->route = (flags & fp->flag_too_short) ? 1 : ((fp->untrimmed_filter && (flags & fp->flag_untrimmed)) ? 2 : 0);
+  return 0;
+}
+
+int64_t csh_format_chunk_bins(const csh_format_params *fp, int64_t n, uint32_t stride, const uint8_t *raw1,
+                              const int64_t *name_off1, const int32_t *name_len1, const uint8_t *seq1,
+                              const uint8_t *qual1, const csh_result *res1, const csh_cap2 *cap2, const uint8_t *raw2,
+                              const int64_t *name_off2, const int32_t *name_len2, const uint8_t *seq2,
+                              const uint8_t *qual2, const csh_result *res2, const uint8_t *bin, int32_t n_bins,
+                              uint8_t *out_binned[2], int64_t *bin_off, int64_t *bin_counts, uint8_t *out[3][2],
+                              int64_t out_len[3][2], int64_t counts[3]) {
+  if (!rc_ready) rc_init();
+  if (!bin || n_bins < 1 || n_bins > 255) return -(n + 1);
+  const int mates = fp->paired ? 2 : 1;
+  const int64_t stride_off = n_bins + 1;
+  for (int m = 0; m < 2; m++)
+    for (int b = 0; b <= n_bins; b++) bin_off[m * stride_off + b] = 0;
+  for (int b = 0; b < n_bins; b++) bin_counts[b] = 0;
+  /* pass 1: bytes per bin and mate (accumulated at bin_off[.. + b + 1]) */
+  for (int64_t i = 0; i < n; i++) {
+    csh_prep p;
+    if (prep_record(fp, i, raw1, name_off1, name_len1, res1, raw2, name_off2, name_len2, res2, &p)) return -(i + 1);
+    if (p.route != 0 || bin[i] >= n_bins) continue;
+    int32_t tag = 0;
+    if (fp->has_umi) tag = 1 + res1[i].cap_len + (fp->paired ? res2[i].cap_len : (cap2 ? cap2[i].len : 0));
+    bin_off[bin[i] + 1] += p.id1l + 2 * (int64_t)(res1[i].stop - res1[i].start) + 6 + tag;
+    if (fp->paired) bin_off[stride_off + bin[i] + 1] += p.id2l + 2 * (int64_t)(res2[i].stop - res2[i].start) + 6 + tag;
+    bin_counts[bin[i]]++;
+  }
+  for (int m = 0; m < mates; m++)
+    for (int b = 0; b < n_bins; b++) bin_off[m * stride_off + b + 1] += bin_off[m * stride_off + b];
+  /* pass 2: bytes */
+  uint8_t *w[3][2];
+  for (int r = 0; r < 3; r++) {
+    counts[r] = 0;
+    for (int m = 0; m < 2; m++) w[r][m] = out[r][m];
+  }
+  int64_t *cur = (int64_t *)malloc((size_t)(2 * stride_off) * sizeof(int64_t));
+  if (!cur) return -(n + 1);
+  for (int64_t j = 0; j < 2 * stride_off; j++) cur[j] = bin_off[j];
+  for (int64_t i = 0; i < n; i++) {
+    csh_prep p;
+    (void)prep_record(fp, i, raw1, name_off1, name_len1, res1, raw2, name_off2, name_len2, res2, &p);
+    int route = p.route;
+    if (route == 0 && bin[i] >= n_bins) route = 2;
+    const uint8_t *nm1 = raw1 + name_off1[i];
+    const uint8_t *s1 = seq1 + (size_t)i * stride, *q1 = qual1 + (size_t)i * stride;
+    const uint8_t *t2;
+    int32_t t2l;
+    const uint8_t *s2 = NULL, *q2 = NULL;
+    if (fp->paired) {
+      s2 = seq2 + (size_t)i * stride;
+      q2 = qual2 + (size_t)i * stride;
+      t2 = s2 + res2[i].cap_off;
+      t2l = res2[i].cap_len;
+    } else {
+      t2 = cap2 ? s1 + cap2[i].off : NULL;
+      t2l = cap2 ? cap2[i].len : 0;
+    }
+    uint8_t *o1 = route == 0 ? out_binned[0] + cur[bin[i]] : w[route][0];
+    uint8_t *e1 = emit(o1, nm1 + p.id1o, p.id1l, s1 + res1[i].cap_off, res1[i].cap_len, t2, t2l, fp->has_umi, s1, q1,
+                       res1[i].start, res1[i].stop, fp->paired ? 0 : fp->reverse_complement);
+    if (route == 0)
+      cur[bin[i]] += e1 - o1;
+    else
+      w[route][0] = e1;
+    if (fp->paired) {
+      const uint8_t *nm2 = raw2 + name_off2[i];
+      uint8_t *o2 = route == 0 ? out_binned[1] + cur[stride_off + bin[i]] : w[route][1];
+      uint8_t *e2 = emit(o2, nm2 + p.id2o, p.id2l, s1 + res1[i].cap_off, res1[i].cap_len, t2, t2l, fp->has_umi, s2, q2,
+                         res2[i].start, res2[i].stop, 0);
+      if (route == 0)
+        cur[stride_off + bin[i]] += e2 - o2;
+      else
+        w[route][1] = e2;
+    }
+    if (route != 0) counts[route]++;
+  }
+  free(cur);
+  counts[0] = 0;
+  for (int b = 0; b < n_bins; b++) counts[0] += bin_counts[b];
+  for (int r = 0; r < 3; r++)
+    for (int m = 0; m < 2; m++) out_len[r][m] = w[r][m] - out[r][m];
+  return 0;
+}

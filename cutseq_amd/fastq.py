@@ -54,6 +54,9 @@ def _lib():
         L.csh_fastq_parse.argtypes = [vp, i64, i64, C.c_uint32, vp, vp, vp, vp, vp]
         L.csh_format_chunk.restype = i64
         L.csh_format_chunk.argtypes = [C.POINTER(_FormatParams), i64, C.c_uint32] + [vp] * 13 + [vp, vp, vp]
+        L.csh_format_chunk_bins.restype = i64
+        L.csh_format_chunk_bins.argtypes = ([C.POINTER(_FormatParams), i64, C.c_uint32] + [vp] * 13 +
+                                            [vp, C.c_int32, vp, vp, vp] + [vp, vp, vp])
         _bound = True
     return L
 
@@ -145,6 +148,7 @@ class Chunk:
     len2: Optional[np.ndarray] = None
 
     _owned: tuple = ()  # (arena, buffer) pairs behind the arrays above
+    bc: Optional[np.ndarray] = None  # demultiplexing runs: barcode index per record (filled by the device)
 
     @property
     def paired(self) -> bool:
@@ -424,17 +428,7 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     until the thread formats its next chunk -- except the streams flagged in ``lease[route][mate]``,
     which are formatted straight into arena buffers and come back as :class:`Lease` objects."""
     L = _lib()
-    fp = _FormatParams()
-    fp.paired = 1 if chunk.paired else 0
-    fp.has_umi = 1 if plan.has_umi else 0
-    fp.untrimmed_filter = 1 if plan.untrimmed_filter else 0
-    fp.reverse_complement = 1 if plan.reverse_complement else 0
-    fp.flag_too_short, fp.flag_untrimmed = abi.CS_F_TOO_SHORT, abi.CS_F_UNTRIMMED
-    suf1 = [s.encode() for s in plan.r1.name_suffixes] + [None, None]
-    fp.suffix1[0], fp.suffix1[1] = suf1[0], suf1[1]
-    if chunk.paired:
-        suf2 = [s.encode() for s in plan.r2.name_suffixes] + [None, None]
-        fp.suffix2[0], fp.suffix2[1] = suf2[0], suf2[1]
+    fp = _format_params(chunk, plan)
     # worst case per record: what the input record held (header, sequence, quality: all inside raw)
     # + '_' + two captures (<= 510) + "@\n\n+\n\n"
     cap_bytes = [len(chunk.raw1) + 528 * chunk.n + 16, (len(chunk.raw2) + 528 * chunk.n + 16) if chunk.paired else 16]
@@ -475,11 +469,83 @@ def format_chunk(chunk: Chunk, plan, res1: np.ndarray, cap2: Optional[np.ndarray
     return views, [int(c) for c in counts]
 
 
-def finish_chunk(chunk: Chunk, plan, res1, cap2, res2, gz: Sequence[Sequence[Optional[bool]]], level: int = 1):
+def _format_params(chunk: Chunk, plan) -> _FormatParams:
+    fp = _FormatParams()
+    fp.paired = 1 if chunk.paired else 0
+    fp.has_umi = 1 if plan.has_umi else 0
+    fp.untrimmed_filter = 1 if plan.untrimmed_filter else 0
+    fp.reverse_complement = 1 if plan.reverse_complement else 0
+    fp.flag_too_short, fp.flag_untrimmed = abi.CS_F_TOO_SHORT, abi.CS_F_UNTRIMMED
+    suf1 = [s.encode() for s in plan.r1.name_suffixes] + [None, None]
+    fp.suffix1[0], fp.suffix1[1] = suf1[0], suf1[1]
+    if chunk.paired:
+        suf2 = [s.encode() for s in plan.r2.name_suffixes] + [None, None]
+        fp.suffix2[0], fp.suffix2[1] = suf2[0], suf2[1]
+    return fp
+
+
+def format_chunk_bins(chunk: Chunk, plan, res1, cap2, res2, bc: np.ndarray, n_bins: int):
+    """Demultiplexed formatting: -> (binned[mate] uint8 array, bin_off[mate][n_bins + 1], bin_counts[n_bins],
+    views[route][mate] (routes 1 and 2 in use), counts[route]).  The arrays in ``binned`` are arena buffers
+    the caller gives back."""
+    L = _lib()
+    fp = _format_params(chunk, plan)
+    cap_bytes = [len(chunk.raw1) + 528 * chunk.n + 16, (len(chunk.raw2) + 528 * chunk.n + 16) if chunk.paired else 16]
+    bufs = _out_buffers(cap_bytes)
+    out_ptrs = ((C.c_void_p * 2) * 3)()
+    for r in range(3):
+        for m in range(2):
+            out_ptrs[r][m] = bufs[r][m].ctypes.data
+    binned = [ARENA.take(cap_bytes[0]), ARENA.take(cap_bytes[1])]
+    binned_ptrs = (C.c_void_p * 2)(binned[0].ctypes.data, binned[1].ctypes.data)
+    bin_off = np.zeros((2, n_bins + 1), dtype=np.int64)
+    bin_counts = np.zeros(n_bins, dtype=np.int64)
+    out_len = ((C.c_int64 * 2) * 3)()
+    counts = (C.c_int64 * 3)()
+    rc = L.csh_format_chunk_bins(
+        C.byref(fp), chunk.n, chunk.stride, _raw_pointer(chunk.raw1), chunk.name_off1.ctypes.data,
+        chunk.name_len1.ctypes.data, chunk.seq1.ctypes.data, chunk.qual1.ctypes.data, res1.ctypes.data,
+        cap2.ctypes.data if cap2 is not None else None,
+        _raw_pointer(chunk.raw2) if chunk.paired else None,
+        chunk.name_off2.ctypes.data if chunk.paired else None, chunk.name_len2.ctypes.data if chunk.paired else None,
+        chunk.seq2.ctypes.data if chunk.paired else None, chunk.qual2.ctypes.data if chunk.paired else None,
+        res2.ctypes.data if res2 is not None else None, bc.ctypes.data, n_bins, binned_ptrs, bin_off.ctypes.data,
+        bin_counts.ctypes.data, out_ptrs, out_len, counts)
+    if rc < 0:
+        for arr in binned:
+            ARENA.give(arr)
+        if -rc > chunk.n:
+            raise ValueError("demultiplexed formatting failed (bad arguments)")
+        raise ValueError(f"Input read IDs not identical in record {int(-rc)} of the chunk")
+    views = [[memoryview(bufs[r][m])[: out_len[r][m]] for m in range(2)] for r in range(3)]
+    return binned, bin_off, bin_counts, views, [int(c) for c in counts]
+
+
+def finish_chunk(chunk: Chunk, plan, res1, cap2, res2, gz: Sequence[Sequence[Optional[bool]]], level: int = 1,
+                 n_bins: int = 0):
     """Worker-thread job of the CLI: format one chunk and turn each wanted stream into what goes to disk:
     one gzip member (bytes), or the plain text in an arena buffer (:class:`Lease`).  ``gz[route][mate]`` is
-    True / False for compressed / plain outputs and None where no file is open.
-    -> (blobs[route][mate], counts)."""
+    True / False for compressed / plain outputs and None where no file is open.  With ``n_bins`` (a
+    demultiplexing run, ``chunk.bc`` filled) the trimmed route is split by barcode: streams 3 .. 3 + n_bins - 1.
+    -> (blobs[stream][mate], counts per stream)."""
+    if n_bins:
+        binned, bin_off, bin_counts, views, counts = format_chunk_bins(chunk, plan, res1, cap2, res2, chunk.bc, n_bins)
+        blobs = [[None, None] for _ in range(3 + n_bins)]
+        try:
+            for r in (1, 2):
+                for m in range(2):
+                    if gz[r][m] is not None and len(views[r][m]):
+                        blobs[r][m] = codec.gzip_member(views[r][m], level) if gz[r][m] else bytes(views[r][m])
+            for b in range(n_bins):
+                for m in range(2 if chunk.paired else 1):
+                    lo, hi = int(bin_off[m][b]), int(bin_off[m][b + 1])
+                    if hi > lo and gz[3 + b][m] is not None:
+                        piece = memoryview(binned[m])[lo:hi]
+                        blobs[3 + b][m] = codec.gzip_member(piece, level) if gz[3 + b][m] else bytes(piece)
+        finally:
+            for arr in binned:
+                ARENA.give(arr)
+        return blobs, [0, counts[1], counts[2]] + [int(c) for c in bin_counts]
     lease = [[gz[r][m] is False for m in range(2)] for r in range(3)]
     views, counts = format_chunk(chunk, plan, res1, cap2, res2, copy=False, lease=lease)
     blobs = [[None, None] for _ in range(3)]

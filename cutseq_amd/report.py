@@ -62,6 +62,8 @@ def account_chunk(totals: dict, tp: TrimPlan, len1: np.ndarray, res1: np.ndarray
 def merge_totals(into: dict, part: dict) -> None:
     into["in_pairs"] += part["in_pairs"]
     for key in ("routes", "in_bp", "out_bp", "written_bp"):
+        if len(into[key]) < len(part[key]):  # demultiplexing runs: one more stream per barcode
+            into[key].extend([0] * (len(part[key]) - len(into[key])))
         for i, v in enumerate(part[key]):
             into[key][i] += v
 
@@ -87,12 +89,17 @@ def _matched(totals: dict, mate: int, slot: Optional[int]) -> int:
     return sum(int(pair[mate]["op_matched"][slot]) for pair in totals["stats"])
 
 
+def written_pairs(totals: dict) -> int:
+    """Pairs that reached a final sink: the trimmed stream, or one stream per barcode when demultiplexing."""
+    return totals["routes"][0] + sum(totals["routes"][3:])
+
+
 def minimal_report(tp: TrimPlan, totals: dict) -> str:
     """Header line + value line, tab separated (cutadapt ``minimal_report`` field order)."""
     fields = ["status", "in_reads", "in_bp", "too_short", "too_long", "too_many_n", "out_reads",
               "w/adapters", "qualtrim_bp", "out_bp"]
     s1, _ = first_adapter(tp.r1)
-    vals = ["OK", totals["in_pairs"], sum(totals["in_bp"]), totals["routes"][1], 0, 0, totals["routes"][0],
+    vals = ["OK", totals["in_pairs"], sum(totals["in_bp"]), totals["routes"][1], 0, 0, written_pairs(totals),
             _matched(totals, 0, s1), _mate_sum(totals, 0, "qualtrim_bp"), totals["written_bp"][0]]
     if tp.paired:
         s2, _ = first_adapter(tp.r2)
@@ -145,7 +152,9 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
         "cutadapt_version": f"5.0+cutseq.amd.{__version__}",
         "engine": {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
                    "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
-                   "per_device": totals["stats"]},
+                   "per_device": totals["stats"],
+                   **({"demultiplexed": dict(zip(totals.get("bin_names") or [], totals["routes"][3:]))}
+                      if tp.demux is not None else {})},
         "input": {"path1": input1, "path2": input2, "paired": True if input2 else False},
         "output": {"output1": output1, "output2": output2, "short1": short1, "short2": short2,
                    "untrimmed1": untrimmed1, "untrimmed2": untrimmed2},
@@ -153,7 +162,7 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
         "read_counts": {
             "input": totals["in_pairs"],
             "filtered": filtered,
-            "output": totals["routes"][0],
+            "output": written_pairs(totals),
             "reverse_complemented": None,
             "read1_with_adapter": _matched(totals, 0, s1) if a1 is not None else None,
             "read2_with_adapter": (_matched(totals, 1, s2) if a2 is not None else None) if paired else None,

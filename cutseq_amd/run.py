@@ -79,6 +79,11 @@ def build_parser() -> argparse.ArgumentParser:
                    help="List all built-in adapter names and their schemes, then exit.")
     p.add_argument("--cutadapt-selection", choices=["4", "3"], default="4",
                    help="Aligner candidate selection to follow: cutadapt >= 4 (default) or 3.x (DESIGN.md section 0).")
+    p.add_argument("--demux-barcodes", type=str, metavar="FILE",
+                   help="Extension: demultiplex on the 5' inline barcode. FILE lists 'name<TAB>sequence' per line (all as "
+                        "long as the scheme's inline barcode); trimmed reads go to <prefix>_<name>_trimmed_R1/2.fastq.gz, "
+                        "reads without any of the barcodes to the untrimmed files. Equals one --ensure-inline-barcode "
+                        "run per barcode.")
     return p
 
 
@@ -136,13 +141,24 @@ def resolve_args(args):
     if not inputs:
         # the reference dies with an IndexError here (run.py:1079-1083); same exit class, clearer message
         _fail("Input file is required.")
-    wants_untrimmed = bool(args.untrimmed_file) or (
+    args.demux = None
+    if args.demux_barcodes:
+        from .demux import read_barcode_file
+        if args.output_file:
+            _fail("--demux-barcodes names the trimmed files itself (<prefix>_<name>_trimmed_R1.fastq.gz): drop -o.")
+        try:
+            args.demux = read_barcode_file(args.demux_barcodes)  # ([names], [sequences])
+        except (OSError, ValueError) as exc:
+            _fail(str(exc))
+    wants_untrimmed = bool(args.untrimmed_file) or args.demux is not None or (
         args.ensure_inline_barcode and _SCHEME_HAS_INLINE.match(args.adapter_scheme) is not None)
     for attr, word in OUTPUT_CLASSES:
         if attr == "untrimmed_file" and not wants_untrimmed:
             args.untrimmed_file = [None] * len(inputs)
         else:
             setattr(args, attr, output_paths(getattr(args, attr), inputs, args.output_prefix, word))
+    if args.demux is not None:  # one pair of trimmed files per barcode instead of the common one
+        args.demux_files = [output_paths(None, inputs, args.output_prefix, f"{name}_trimmed") for name in args.demux[0]]
     return args
 
 
@@ -162,6 +178,8 @@ def settings_from_args(args) -> CutadaptConfig:
     st.force_trim_min_length = args.force_trim_min_length
     st.force_anywhere = args.force_anywhere
     st.select_rule = abi.CS_SELECT_LEFTMOST if args.cutadapt_selection == "4" else abi.CS_SELECT_SCORE
+    if getattr(args, "demux", None) is not None:
+        st.demux_barcodes = list(args.demux[1])
     return st
 
 
@@ -254,10 +272,13 @@ class _DeviceWorker(threading.Thread):
                 if paired:
                     owned.append(fastq.PINNED.take(chunk.n * 8))
                     out2 = owned[-1][: chunk.n * 8].view(abi.RESULT_DTYPE)
+                if self.tp.demux is not None:
+                    owned.append(fastq.PINNED.take(chunk.n))
+                    chunk.bc = owned[-1][: chunk.n]
                 chunk._owned = chunk._owned + tuple((fastq.PINNED, b) for b in owned)
                 slot = n % self.SLOTS
                 res = self.engine.submit(slot, chunk.seq1, chunk.qual1, chunk.len1, chunk.seq2, chunk.qual2,
-                                         chunk.len2, out=(out1, cap2, out2))
+                                         chunk.len2, out=(out1, cap2, out2), bc=chunk.bc)
                 inflight.append((k, slot, chunk, res))
                 n += 1
             while inflight:
@@ -295,10 +316,14 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     def mk(names):
         return [fastq.OutputFile(n) if n else None for n in names]
 
-    trimmed = mk(args.output_file)
+    n_bins = len(tp.demux.barcodes) if tp.demux is not None else 0
+    trimmed = mk(args.output_file) if not n_bins else [None] * len(args.output_file)
     if paired and tp.swap_outputs:
         trimmed = trimmed[::-1]
     outs = [trimmed, mk(args.short_file), mk(args.untrimmed_file)]
+    for names in (args.demux_files if n_bins else ()):  # streams 3 .. : the trimmed reads of one barcode each
+        files = mk(names)
+        outs.append(files[::-1] if paired and tp.swap_outputs else files)
     # which (route, mate) streams go to disk, and whether they are gzip
     gz = [[(fh.gz if fh is not None else None) for fh in (group + [None])[:2]] for group in outs]
 
@@ -313,7 +338,7 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     def finish(chunk, r1, cap2, r2):
         """Pool job: records -> bytes on their way to disk; also this chunk's share of the report."""
         try:
-            blobs, counts = fastq.finish_chunk(chunk, tp, r1, cap2, r2, gz)
+            blobs, counts = fastq.finish_chunk(chunk, tp, r1, cap2, r2, gz, n_bins=n_bins)
             part = report.new_totals()
             report.account_chunk(part, tp, chunk.len1, r1, chunk.len2 if paired else None, r2 if paired else None)
             part["routes"] = counts
@@ -338,7 +363,7 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
                     _, chunk, (r1, cap2, r2) = waiting.pop(next_k)
                     next_k += 1
                     fut = pool.submit(finish, chunk, r1, cap2, r2)
-                    for route in range(3):
+                    for route in range(len(outs)):
                         for m in range(2 if paired else 1):
                             if outs[route][m] is not None:
                                 outs[route][m].write_job(fut, route, m)
@@ -402,6 +427,7 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
         raise first_error
     stats = [w.stats for w in workers if w.stats is not None]
     totals["seconds"] = time.perf_counter() - t0
+    totals["bin_names"] = list(args.demux[0]) if n_bins else None
     totals["stats"] = stats
     totals["devices"] = devices
     return totals

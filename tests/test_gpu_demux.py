@@ -128,3 +128,61 @@ def test_demux_table_matches_the_oracle_on_every_prefix():
         assert np.array_equal((op.table[mine] >> 8) & 0xF, o1["start"][mine])  # ... and removes as many bases
     assert np.array_equal((op.table & 0xFF) == abi.CS_DEMUX_NONE, n_match == 0)
     assert np.array_equal((op.table & 0x4000) != 0, n_match > 1)
+
+
+def test_cli_demultiplexes_like_independent_runs(tmp_path, monkeypatch):
+    """cutseq --demux-barcodes through the whole host path (two engines, several chunks): every barcode's
+    trimmed files hold exactly what an --ensure-inline-barcode run with that one barcode would have written
+    to its trimmed files; the untrimmed files hold the pairs no barcode claims."""
+    import gzip
+    import json
+    import zlib
+
+    from cutseq_amd import hostfmt, run as cli
+
+    rng = random.Random(11)
+    length, count, n = 8, 16, 40_000
+    codes = barcode_set(rng, count, length, 5)
+    names = [f"bc{i:02d}" for i in range(count)]
+    batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=21)
+    plant_barcodes(rng, batch, codes, length)
+    names1 = [f"SIM:{i} 1:N:0:X".encode() for i in range(n)]
+    names2 = [f"SIM:{i} 2:N:0:X".encode() for i in range(n)]
+    in1, in2 = str(tmp_path / "d_R1.fastq.gz"), str(tmp_path / "d_R2.fastq.gz")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1, gz_members=7000)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=9000)
+    table = tmp_path / "barcodes.tsv"
+    table.write_text("# name\tsequence\n" + "".join(f"{a}\t{b}\n" for a, b in zip(names, codes)))
+    monkeypatch.setenv("CUTSEQ_DEVICES", "0,0")
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "6000")
+    prefix = str(tmp_path / "dm")
+    cli.main(["-a", scheme_with(codes[0]), "--demux-barcodes", str(table), "-O", prefix, "--json-file",
+              str(tmp_path / "r.json"), in1, in2])
+
+    def gunzip(path):
+        with gzip.open(path, "rb") as fh:
+            return fh.read()
+
+    st = planmod.CutadaptConfig()
+    st.ensure_inline_barcode = True
+    claimed = np.zeros(n, dtype=int)
+    total_trimmed = 0
+    for name, code in zip(names, codes):
+        one = planmod.compile_paired(BarcodeConfig(scheme_with(code)), st)
+        (o1, _, _), (o2, _, _) = util.oracle_run(one, batch, threads=8)
+        recs = util.format_batch(one, batch, names1, names2, o1, None, o2)
+        want1 = b"".join(x[1] for x in recs if x[0] == hostfmt.ROUTE_TRIMMED)
+        want2 = b"".join(x[2] for x in recs if x[0] == hostfmt.ROUTE_TRIMMED)
+        assert gunzip(f"{prefix}_{name}_trimmed_R1.fastq.gz") == want1, name
+        assert gunzip(f"{prefix}_{name}_trimmed_R2.fastq.gz") == want2, name
+        claimed += np.array([x[0] == hostfmt.ROUTE_TRIMMED for x in recs])
+        total_trimmed += sum(1 for x in recs if x[0] == hostfmt.ROUTE_TRIMMED)
+        last = recs
+    assert claimed.max() <= 1  # unambiguous barcode set: no pair is trimmed by two runs
+    # pairs no run trims and that are not too short: identical (untrimmed) in every run -> the untrimmed files
+    unassigned = [x for x in last if x[0] == hostfmt.ROUTE_UNTRIMMED]
+    got_untr = gunzip(f"{prefix}_untrimmed_R1.fastq.gz")
+    rep = json.loads((tmp_path / "r.json").read_text())
+    assert sum(rep["engine"]["demultiplexed"].values()) == total_trimmed == rep["read_counts"]["output"]
+    assert got_untr.count(b"\n") // 4 == n - total_trimmed - rep["read_counts"]["filtered"]["too_short"]
+    assert zlib.crc32(got_untr) != 0 and len(unassigned) >= got_untr.count(b"\n") // 4
