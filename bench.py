@@ -54,6 +54,34 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH
 VALU_CYCLES_PER_INSTR = 2.65
 # BASELINE config 4: inline barcode + 8-nt UMI + dual adapters, --ensure-inline-barcode
 CONFIG4_SCHEME = "ACACGACGCTCTTCCGATCT(ATCACG)NNNNNNNN>AGATCGGAAGAGCACACGTC"
+# BASELINE config 5 (extension, not a reference capability): 96-plex inline-barcode demultiplex + dual adapters + q-trim
+CONFIG5_PLEX, CONFIG5_LEN = 96, 8
+
+
+def config5_barcodes(seed: int = 96):
+    """96 barcodes of 8 nt, pairwise edit distance >= 3 (seeded greedy pick)."""
+    import random
+    rng = random.Random(seed)
+
+    def dist(a, b):
+        prev = list(range(len(b) + 1))
+        for i, ca in enumerate(a, 1):
+            cur = [i]
+            for j, cb in enumerate(b, 1):
+                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+            prev = cur
+        return prev[-1]
+
+    codes = []
+    while len(codes) < CONFIG5_PLEX:
+        c = "".join(rng.choice("ACGT") for _ in range(CONFIG5_LEN))
+        if all(dist(c, o) >= 3 for o in codes):
+            codes.append(c)
+    return codes
+
+
+def config5_scheme(codes):
+    return f"ACACGACGCTCTTCCGATCT({codes[0]})>AGATCGGAAGAGCACACGTC"
 
 
 def parse_args():
@@ -62,7 +90,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4_000_000, help="read pairs per step (resident batch)")
-    ap.add_argument("--workload", choices=["config3", "config2", "config4"], default="config3")
+    ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the HBM copy-bandwidth probe")
@@ -78,6 +106,11 @@ def make_plan(workload: str, use_filter: bool):
         st = planmod.CutadaptConfig()
         st.ensure_inline_barcode = True
         tp = planmod.compile_paired(BarcodeConfig(CONFIG4_SCHEME), st)
+    elif workload == "config5":
+        codes = config5_barcodes()
+        st = planmod.CutadaptConfig()
+        st.demux_barcodes = codes
+        tp = planmod.compile_paired(BarcodeConfig(config5_scheme(codes)), st)
     else:
         st = planmod.CutadaptConfig()
         st.trim_polyA = True
@@ -117,7 +150,20 @@ def main():
     # every rank trims its own shard of the read stream (weak scaling: world * n reads in all), no exchange step
     first, last = shard.shard_bounds(world * n, rank, world)
     assert last - first == n
-    if args.workload == "config4":
+    if args.workload == "config5":
+        codes = config5_barcodes()
+        batch = synth.generate_pairs(n, READ_LEN, config5_scheme(codes), first_index=first)
+        # every pair gets one of the 96 barcodes (2 % get none of them), 1 % sequencing error per base on top
+        rng = np.random.default_rng(first + 5)
+        table = np.frombuffer("".join(codes).encode(), dtype=np.uint8).reshape(CONFIG5_PLEX, CONFIG5_LEN)
+        pick = rng.integers(0, CONFIG5_PLEX, size=n)
+        bc_bases = table[pick].copy()
+        foreign = rng.random(n) < 0.02
+        bc_bases[foreign] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(int(foreign.sum()), CONFIG5_LEN))]
+        err = rng.random((n, CONFIG5_LEN)) < 0.01
+        bc_bases[err] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(err.sum()))]
+        batch.seq1[:, :CONFIG5_LEN] = bc_bases
+    elif args.workload == "config4":
         batch = synth.generate_pairs(n, READ_LEN, CONFIG4_SCHEME, first_index=first)
     elif paired:
         batch = synth.generate_pairs(n, READ_LEN, first_index=first)
@@ -130,13 +176,15 @@ def main():
 
     d = {"seq1": up(batch.seq1), "qual1": up(batch.qual1), "len1": up(batch.len1.view(np.int16))}
     out1 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
-    r1 = abi.cs_reads(d["seq1"].data_ptr(), d["qual1"].data_ptr(), d["len1"].data_ptr(), out1.data_ptr(), None)
+    bc1 = torch.empty(n, dtype=torch.uint8, device=dev) if args.workload == "config5" else None
+    r1 = abi.cs_reads(d["seq1"].data_ptr(), d["qual1"].data_ptr(), d["len1"].data_ptr(), out1.data_ptr(), None,
+                      bc1.data_ptr() if bc1 is not None else None)
     r2 = None
     out2 = None
     if paired:
         d.update(seq2=up(batch.seq2), qual2=up(batch.qual2), len2=up(batch.len2.view(np.int16)))
         out2 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
-        r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None)
+        r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None, None)
 
     eng = TrimEngine(tp, device=gpu_index, slots=0)
     # an explicit (non-default) stream: its handle is what the C ABI launches on, and the
@@ -177,7 +225,7 @@ def main():
 
     units_per_step = n
     value = world * args.steps * units_per_step / elapsed / 1e6
-    bytes_per_unit = (2 if paired else 1) * (2 * READ_LEN + 8)
+    bytes_per_unit = (2 if paired else 1) * (2 * READ_LEN + 8) + (1 if args.workload == "config5" else 0)  # + barcode byte
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = bytes_per_unit * units_per_step / avg_kernel_s / 1e9
     traffic = valu_insts = None
@@ -210,10 +258,13 @@ def main():
                 "config2": f"BASELINE config 2: 150 bp single-end, 3' adapter AGATCGGAAGAGC e=0.1, {args.steps} steps x {n} reads",
                 "config4": "BASELINE config 4: 2x150 bp pairs, custom scheme with inline barcode + 8 nt UMI + dual adapters, "
                            f"--ensure-inline-barcode, {args.steps} steps x {n} resident pairs per GPU",
+                "config5": "BASELINE config 5 (extension): 2x150 bp pairs, 96-plex 8-nt inline-barcode demultiplex + dual "
+                           f"adapters + q-trim in one pass, {args.steps} steps x {n} resident pairs per GPU",
             }[args.workload],
             "pairs_per_step_per_gpu": n,
             "read_len": READ_LEN,
-            "scheme": {"config3": "TAKARAV3", "config2": "-a AGATCGGAAGAGC", "config4": CONFIG4_SCHEME}[args.workload],
+            "scheme": {"config3": "TAKARAV3", "config2": "-a AGATCGGAAGAGC", "config4": CONFIG4_SCHEME,
+                       "config5": "P5(96 x 8 nt)>P7 --demux-barcodes"}[args.workload],
             "prefilter": not args.no_filter,
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
@@ -264,7 +315,8 @@ def main():
         result["roofline"]["frac_of_copy_measured"] = round(achieved / copy_gbps, 5)
         del src, dst
 
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "config5":
+        # (config 5 has no single CPU counterpart: its parity definition is 96 oracle runs, tests/test_gpu_demux.py)
         import oracle  # the checker, timed as the CPU baseline; never part of the product path
         m = min(args.cpu_sample, n)
         threads = oracle.host_threads()
