@@ -1,0 +1,9 @@
+#!/bin/bash
+# A/B of kernel builds on ONE box in ONE call: tools/ab_libs.sh libA.so libB.so [rounds] -> M pairs/s per run, alternating
+A=$1; B=$2; R=${3:-3}
+for i in $(seq $R); do
+  for lib in $A $B; do
+    v=$(CUTSEQ_HIP_LIB=$GRAFT_REPO_ROOT/$lib python3 bench.py --steps 25 --warmup 3 --cpu-sample 0 --no-copy-probe 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms_last_step'])")
+    echo "$lib $v"
+  done
+done
