@@ -102,7 +102,7 @@ struct cs_engine {
   std::vector<void *> d_tables;           // device copies of the CS_OP_DEMUX tables
   uint32_t defer_capacity = 0;            // records per mate
   // tuning knobs, read once from the environment when the engine is created
-  uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 0;
+  uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 1;  // batch knob: see trim_kernel (resolve)
   bool knob_units = false;
   uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 75;
 };

@@ -24,6 +24,7 @@
  * run compares two different programs.
  */
 #include <pthread.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,8 +68,14 @@ static int better_candidate(int select_rule, int m, int n, const match_t *best, 
  * thr[L] = floor(L * max_error_rate) stands for `cost <= L * max_error_rate`.
  * out = (ref_start, ref_stop, query_start, query_stop, score, errors); returns 1 on a hit.
  */
-int cs_oracle_locate2(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *thr, int k,
-                      int flags, int min_overlap, int select_rule, int indel_tie, int out[6]) {
+static uint8_t ascii_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+/* `query` is read in place: character j - 1 of the aligner's query is query[(j - 1) * qstep], upper-cased when
+ * `fold` is set -- RightmostFrontAdapter walks the read backwards (qstep = -1 from its last base) and
+ * match_to aligns sequence.upper(), neither needs a copy of the read. */
+static int locate_strided(const uint8_t *ref, int m, const uint8_t *query, int qstep, int fold, int n,
+                          const uint8_t *thr, int k, int flags, int min_overlap, int select_rule, int indel_tie,
+                          int out[6]) {
   const int start_in_ref = flags & CS_REF_START, start_in_query = flags & CS_QUERY_START;
   const int stop_in_ref = flags & CS_REF_END, stop_in_query = flags & CS_QUERY_STOP;
   entry_t column[CS_MAX_ADAPTER + 1];
@@ -111,9 +118,11 @@ int cs_oracle_locate2(const uint8_t *ref, int m, const uint8_t *query, int n, co
       column[0].origin = j;
     else
       column[0].cost = j;
+    const uint8_t qraw = query[(ptrdiff_t)(j - 1) * qstep];
+    const uint8_t qc = fold ? ascii_upper(qraw) : qraw;
     for (i = 1; i <= last; i++) {
       int cost, origin, score;
-      if (ref[i - 1] == query[j - 1]) {
+      if (ref[i - 1] == qc) {
         cost = diag.cost;
         origin = diag.origin;
         score = diag.score + MATCH_SCORE;
@@ -196,6 +205,11 @@ int cs_oracle_locate2(const uint8_t *ref, int m, const uint8_t *query, int n, co
   return 1;
 }
 
+int cs_oracle_locate2(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *thr, int k,
+                      int flags, int min_overlap, int select_rule, int indel_tie, int out[6]) {
+  return locate_strided(ref, m, query, 1, 0, n, thr, k, flags, min_overlap, select_rule, indel_tie, out);
+}
+
 /* the SURVEY appendix B.2 tie order, kept under the old name for callers that do not care */
 int cs_oracle_locate(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *thr, int k,
                      int flags, int min_overlap, int select_rule, int out[6]) {
@@ -219,23 +233,17 @@ static int find_exact(const uint8_t *text, int n, const uint8_t *pat, int m) {
  * `op->seq` is already reversed for the rightmost variant, so find-on-reversed == rfind.
  * Returns 1 and (rstart, rstop) in forward read coordinates.
  */
-static uint8_t ascii_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
-
 int cs_oracle_match2(const cs_op *op, const cs_params *params, const uint8_t *read, int n, int *rstart,
                      int *rstop) {
-  uint8_t buf[65536];
-  const uint8_t *q = read;
   const int select_rule = params->select_rule, fold = params->case_rule == CS_CASE_FOLD;
   int m = op->m, qs, qe, hit = 0;
-  if (op->reversed || fold) {
+  if (op->shortcut == CS_SHORTCUT_FIND) { /* cutadapt <= 2.x str.find / str.rfind: works on a copy (opt-in path) */
+    uint8_t buf[65536];
     for (int i = 0; i < n; i++) {
       uint8_t c = read[op->reversed ? n - 1 - i : i];
       buf[i] = fold ? ascii_upper(c) : c;
     }
-    q = buf;
-  }
-  if (op->shortcut == CS_SHORTCUT_FIND) {
-    int pos = find_exact(q, n, op->seq, m);
+    int pos = find_exact(buf, n, op->seq, m);
     if (pos >= 0) {
       qs = pos;
       qe = pos + m;
@@ -244,8 +252,9 @@ int cs_oracle_match2(const cs_op *op, const cs_params *params, const uint8_t *re
   }
   if (!hit) {
     int out[6];
-    if (!cs_oracle_locate2(op->seq, m, q, n, op->thr, op->k, op->align_flags, op->min_overlap, select_rule,
-                           params->indel_tie, out))
+    const uint8_t *q0 = op->reversed ? read + (n > 0 ? n - 1 : 0) : read;
+    if (!locate_strided(op->seq, m, q0, op->reversed ? -1 : 1, fold, n, op->thr, op->k, op->align_flags,
+                        op->min_overlap, select_rule, params->indel_tie, out))
       return 0;
     qs = out[2];
     qe = out[3];
