@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: M read-pairs/s of the fused trimming kernel (BASELINE.json metric).
+"""Headline benchmark: M read-pairs/s of the trimming kernels (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 25 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \

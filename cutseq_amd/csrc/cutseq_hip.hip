@@ -1,4 +1,4 @@
-// cutseq_hip.hip -- C ABI (include/cutseq_hip.h) + launch code of the fused trimming kernel.
+// cutseq_hip.hip -- C ABI (include/cutseq_hip.h) + launch code of the trimming kernels (scan + resolve).
 // Build: hipcc -O3 --offload-arch=gfx950 -fPIC -shared -o libcutseq_hip.so cutseq_hip.hip
 // gfx950 (MI355X) only; there is no CPU path in this library.
 #include <hip/hip_runtime.h>

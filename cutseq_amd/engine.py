@@ -1,4 +1,4 @@
-"""Batch engine: one :class:`TrimEngine` per GPU drives the fused HIP kernel.
+"""Batch engine: one :class:`TrimEngine` per GPU drives the two HIP kernels (scan, resolve).
 
 Counterpart of ``runner.run(pipeline, Progress(), outfiles)`` (cutseq/run.py:473, 794):
 where cutadapt loops over reads calling modifiers, this hands whole batches (SoA rows,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU ablation: time plan variants of the fused kernel on one resident batch (kernel-only)."""
+"""GPU ablation: time plan variants of the two kernels on one resident batch (kernel-only)."""
 import ctypes as C
 import sys
 from pathlib import Path
