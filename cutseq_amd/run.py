@@ -418,13 +418,13 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
                     fh.close()
                 except BaseException as exc:  # keep closing the others; report the first failure
                     first_error = first_error or exc
-        fastq.PINNED.free_pinned()
     if first_error is None and failure:
         first_error = failure[0]
     if first_error is None:
         first_error = next((w.error for w in workers if w.error is not None), None)
     if first_error is not None:
-        raise first_error
+        raise first_error  # (the pinned arena is left alone: parse / format jobs of the pool may still hold its buffers)
+    fastq.PINNED.free_pinned()  # every chunk has been written and released
     stats = [w.stats for w in workers if w.stats is not None]
     totals["seconds"] = time.perf_counter() - t0
     totals["bin_names"] = list(args.demux[0]) if n_bins else None

@@ -317,3 +317,99 @@ class SynthLike:
         self.n, self.stride = c.n, c.stride
         self.seq1, self.qual1, self.len1 = c.seq1, c.qual1, c.len1
         self.seq2, self.qual2, self.len2 = c.seq2, c.qual2, c.len2
+
+
+# ---------------------------------------------------------------- gzip codec (libdeflate / BGZF / zlib)
+
+
+def _bgzf_block(data: bytes) -> bytes:
+    import struct
+    import zlib
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = c.compress(data) + c.flush()
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(body) + 25) + body +
+            struct.pack("<II", zlib.crc32(data), len(data)))
+
+
+def _codec_files(tmp_path):
+    import random
+    from cutseq_amd import codec
+    rng = random.Random(4)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(60)), b"I" * 60) for i in range(20000))
+    files = {
+        "single": gzip.compress(text, 1),
+        "members": b"".join(codec.gzip_member(text[i:i + 300_000], 1) for i in range(0, len(text), 300_000)),
+        "bgzf": b"".join(_bgzf_block(text[i:i + 65280]) for i in range(0, len(text), 65280)) + _bgzf_block(b""),
+        "padded": gzip.compress(text, 1) + b"\0" * 4096,
+        "bgzf_then_plain_member": _bgzf_block(text[:50000]) + gzip.compress(text[50000:], 1),
+    }
+    paths = {}
+    for name, blob in files.items():
+        paths[name] = tmp_path / f"{name}.gz"
+        paths[name].write_bytes(blob)
+    return text, paths
+
+
+def _inflate(path, pool=None):
+    from cutseq_amd import codec
+    src = codec.GzipSource(str(path), pool)
+    try:
+        return b"".join(bytes(memoryview(arr)[:n]) for arr, n in src.blocks())
+    finally:
+        src.close()
+
+
+def test_codec_every_container_and_both_backends(tmp_path, monkeypatch):
+    """single member, this tool's own multi-member output, BGZF (parallel block inflate), zero padding, mixed
+    containers -- through libdeflate and through the zlib fallback; compressor output readable by gzip."""
+    from concurrent.futures import ThreadPoolExecutor
+    from cutseq_amd import codec
+    text, paths = _codec_files(tmp_path)
+    with ThreadPoolExecutor(3) as pool:
+        for name, path in paths.items():
+            assert _inflate(path) == text, name
+            assert _inflate(path, pool) == text, name
+    assert gzip.decompress(codec.gzip_member(text, 1)) == text
+    assert gzip.decompress(codec.gzip_member(b"", 1)) == b""
+    if codec.libdeflate() is not None:
+        monkeypatch.setattr(codec, "_lib", None)  # zlib only (a box without libdeflate.so)
+        monkeypatch.setattr(codec, "_lib_tried", True)
+        for name, path in paths.items():
+            assert _inflate(path) == text, name
+        assert gzip.decompress(codec.gzip_member(text, 1)) == text
+
+
+def test_codec_truncated_and_corrupt_input(tmp_path):
+    text, paths = _codec_files(tmp_path)
+    cut = tmp_path / "cut.gz"
+    cut.write_bytes(paths["single"].read_bytes()[:-200])
+    with pytest.raises(OSError):
+        _inflate(cut)
+    bad = bytearray(paths["members"].read_bytes())
+    bad[len(bad) // 2] ^= 0xFF
+    broken = tmp_path / "bad.gz"
+    broken.write_bytes(bytes(bad))
+    with pytest.raises(OSError):
+        _inflate(broken)
+    empty = tmp_path / "empty.gz"
+    empty.write_bytes(b"")
+    assert _inflate(empty) == b""
+
+
+def test_reader_takes_bgzf_and_multi_member_input(tmp_path):
+    """read_chunks on BGZF / multi-member files yields the same records as on the plain text."""
+    text, paths = _codec_files(tmp_path)
+    plain = tmp_path / "plain.fq"
+    plain.write_bytes(text)
+    def records(path):
+        out = []
+        for ch in fastq.read_chunks(str(path), chunk_reads=3000):
+            for i in range(ch.n):
+                out.append((bytes(ch.raw1[ch.name_off1[i]: ch.name_off1[i] + ch.name_len1[i]]),
+                            bytes(ch.seq1[i, : ch.len1[i]])))
+            ch.release()
+        return out
+    want = records(plain)
+    assert len(want) == 20000
+    for name in ("bgzf", "members", "bgzf_then_plain_member"):
+        assert records(paths[name]) == want, name
