@@ -469,3 +469,51 @@ def test_inexact_occurrence_in_front_of_an_exact_one(rule):
     rev = util.batch_from_reads([(s[::-1], q) for s, q in reads])
     tp = one_adapter_plan(ad[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, True, 0, rule, True)
     run_both(tp, rev, threads=8)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_hits_that_settle_in_the_filter_stress(seed):
+    """The filter settles exact and substitution-only hits without the DP.  Reads built to sit on
+    every edge of those arguments: substitutions only / one indel, repeats and low-complexity adapters (ties),
+    hits at the very start (alignments that begin in the first column), at the very end (rows against
+    full-length cells), two copies at every distance, reads barely longer than m + k -- all flag sets that take
+    the path, both selection rules, both tie orders, filter on (and the full DP as the reference point through
+    the oracle)."""
+    rng = random.Random(500 + seed)
+    for trial in range(16):
+        alpha = rng.choice(["ACGT", "ACGT", "AC", "ACG"])
+        m = rng.choice([6, 8, 12, 13, 16, 20, 24, 31, 32])
+        ref = util.random_dna(rng, m, alpha) if rng.random() < 0.7 else (util.random_dna(rng, 3, alpha) * 12)[:m]
+        rate = rng.choice([0.1, 0.15, 0.2, 0.25, 0.34])
+        k = int(rate * m)
+        where = rng.choice(["BACK", "BACK", "BACK_NI", "PREFIX", "SUFFIX", "FRONT", "ANYWHERE"])
+        rightmost = where == "BACK" and rng.random() < 0.4
+        mo = rng.choice([1, 3, min(10, m), m])
+        reads = []
+        for _ in range(4000):
+            hit = list(ref)
+            for _s in range(rng.choice([0, 0, 1, 1, 2, 3, k, k + 1])):  # substitutions
+                hit[rng.randrange(m)] = rng.choice(alpha)
+            hit = "".join(hit)
+            if rng.random() < 0.15:
+                hit = util.mutate(rng, hit, 1, alpha)  # an indel or another substitution
+            cut = rng.random()
+            if cut < 0.25:
+                hit = hit[: rng.randint(1, max(1, len(hit)))]  # partial copy (meant for the read end)
+            elif cut < 0.35:
+                hit = hit[rng.randint(0, max(0, len(hit) - 1)):]  # partial copy (meant for the read start)
+            left = util.random_dna(rng, rng.choice([0, 0, 1, 2, k, m, m + k - 1, m + k, m + k + 1, 40]), alpha)
+            right = util.random_dna(rng, rng.choice([0, 0, 0, 1, 2, k, m // 2, m, 30]), alpha)
+            s = left + hit + right
+            if rng.random() < 0.2:  # a second copy somewhere behind
+                s += util.random_dna(rng, rng.choice([0, 1, m // 2, m])) + hit[: rng.randint(1, max(1, len(hit)))]
+            if rightmost:
+                s = s[::-1]
+            reads.append((s, "I" * len(s)))
+        batch = util.batch_from_reads(reads)
+        seq = ref[::-1] if rightmost else ref
+        remove = abi.CS_REMOVE_BEFORE if (rightmost or where in ("PREFIX", "FRONT")) else abi.CS_REMOVE_AFTER
+        for rule in (0, 1):
+            tie = rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION])
+            tp = one_adapter_plan(seq, rate, mo, WHERE[where], remove, rightmost, 0, rule, True, tie)
+            run_both(tp, batch, threads=8)
