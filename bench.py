@@ -5,8 +5,13 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (one cs_trim_device call = scan kernel + resolve kernel over both
-mates) over a synthetic batch of ``--pairs`` 2x150 bp read pairs that is already resident in HBM.  The
+A "step" is one pass of the hot path (one cs_trim_device_pipelined call = scan kernel + resolve kernel over
+both mates) over a synthetic batch of ``--pairs`` 2x150 bp read pairs that is already resident in HBM.
+Steps are pipelined the way the runner keeps batches in flight: the scan kernels follow each other on one
+stream, each step's resolve kernel (3 % of the reads, a few latency-bound waves) runs on the engine's
+resolve stream under the NEXT step's scan kernel, every step writes its own result arrays, and the timed
+region ends with cs_join + a device synchronize, so all K steps are complete inside it (``--serial``: both
+kernels of a step on one stream, nothing overlaps).  The
 default 25 steps x 4 M pairs = the 100 M-pair workload of BASELINE.json config 3 (TAKARAV3 +
 --trim-polyA: UMI + masks + poly-T/A + q-trim).  Reads shard across ranks with no
 collective (weak scaling: every GPU gets its own 4 M-pair batch); torch.distributed is only
@@ -14,13 +19,14 @@ used for the barrier and the max-over-ranks of the elapsed time.
 
 One JSON line on rank 0, with
   roofline      algorithmic bytes (616 B/pair = 2 x (150 seq + 150 qual + 8 result)) per
-                launch / average time of the launch's two kernels from HIP events on the launch
-                stream, against the 8 TB/s HBM3E peak; ``traffic`` (HBM bytes per launch) is REPLAYED
+                launch / average duration of the dominant kernel (the scan kernel; --serial: both kernels)
+                from HIP events on the launch stream, against the 8 TB/s HBM3E peak (``frac_step``: the
+                same bytes over the whole step time); ``traffic`` (HBM bytes per launch) is REPLAYED
                 from the committed counter passes (profiles/r02_pmc_summary.json), not measured in
                 this run;
   roofline_valu the bound that actually governs: VALU wave-instructions per launch (same replayed
-                counter file) x the measured issue cost per instruction / (1024 SIMDs x clock x
-                kernel time of THIS run);
+                counter file, both kernels) x the measured issue cost per instruction / (1024 SIMDs x
+                clock x step time of THIS run);
   cpu_baseline  the CPU oracle (own scalar C restatement of the cutseq->cutadapt chain --
                 cutadapt itself is not installable here) timed on this box's host cores on a
                 bounded sample of the same batch; the GPU results for that sample are
@@ -93,6 +99,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
+    ap.add_argument("--serial", action="store_true", help="both kernels of a step on one stream (no overlap between steps)")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the HBM copy-bandwidth probe")
     ap.add_argument("--traffic-json", type=str, default=str(ROOT / "profiles" / "r02_pmc_summary.json"),
                     help="JSON with HBM bytes per launch measured in separate rocprofv3 --pmc passes (tools/pmc.sh)")
@@ -175,16 +182,22 @@ def main():
         return torch.from_numpy(a).to(dev, non_blocking=False)
 
     d = {"seq1": up(batch.seq1), "qual1": up(batch.qual1), "len1": up(batch.len1.view(np.int16))}
-    out1 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
-    bc1 = torch.empty(n, dtype=torch.uint8, device=dev) if args.workload == "config5" else None
-    r1 = abi.cs_reads(d["seq1"].data_ptr(), d["qual1"].data_ptr(), d["len1"].data_ptr(), out1.data_ptr(), None,
-                      bc1.data_ptr() if bc1 is not None else None)
-    r2 = None
-    out2 = None
     if paired:
         d.update(seq2=up(batch.seq2), qual2=up(batch.qual2), len2=up(batch.len2.view(np.int16)))
-        out2 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
-        r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None, None)
+    # one set of result arrays per step in flight (the engine lets a call start once the call three before it is done)
+    n_sets = 1 if args.serial else 3
+    sets = []
+    for _ in range(n_sets):
+        out1 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+        bc1 = torch.empty(n, dtype=torch.uint8, device=dev) if args.workload == "config5" else None
+        r1 = abi.cs_reads(d["seq1"].data_ptr(), d["qual1"].data_ptr(), d["len1"].data_ptr(), out1.data_ptr(), None,
+                          bc1.data_ptr() if bc1 is not None else None)
+        r2 = out2 = None
+        if paired:
+            out2 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+            r2 = abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), out2.data_ptr(), None, None)
+        sets.append((r1, r2, out1, out2, bc1))
+    out1, out2 = sets[0][2], sets[0][3]
 
     eng = TrimEngine(tp, device=gpu_index, slots=0)
     # an explicit (non-default) stream: its handle is what the C ABI launches on, and the
@@ -193,17 +206,19 @@ def main():
     sh = C.c_void_p(stream.cuda_stream)
     assert sh.value, "expected a non-null hipStream_t"
 
-    def step():
-        eng.trim_device(r1, r2, n, stride, stream=sh)
+    def step(i):
+        r1, r2 = sets[i % n_sets][:2]
+        eng.trim_device(r1, r2, n, stride, stream=sh, pipelined=not args.serial)
 
     def barrier():
+        eng.join(sh)
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     barrier()
     eng.stats(reset=True)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -212,8 +227,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         starts[i].record(stream)
-        step()
-        stops[i].record(stream)
+        step(i)
+        stops[i].record(stream)  # serial: behind both kernels; pipelined: behind the scan kernel
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
@@ -227,6 +242,7 @@ def main():
     value = world * args.steps * units_per_step / elapsed / 1e6
     bytes_per_unit = (2 if paired else 1) * (2 * READ_LEN + 8) + (1 if args.workload == "config5" else 0)  # + barcode byte
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    step_s = elapsed / args.steps
     achieved = bytes_per_unit * units_per_step / avg_kernel_s / 1e9
     traffic = valu_insts = None
     traffic_source = None
@@ -266,6 +282,7 @@ def main():
             "scheme": {"config3": "TAKARAV3", "config2": "-a AGATCGGAAGAGC", "config4": CONFIG4_SCHEME,
                        "config5": "P5(96 x 8 nt)>P7 --demux-barcodes"}[args.workload],
             "prefilter": not args.no_filter,
+            "pipeline": "serial" if args.serial else "resolve kernel of step i under the scan kernel of step i+1 (2 streams, 3 result sets)",
             "parallelism": f"shard{world}" if world > 1 else "single",
         },
         "roofline": {
@@ -276,7 +293,11 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "kernel": "csdev::trim_kernel<.., MODE_SCAN> + <.., MODE_RESOLVE> (one launch of each per step)",
+            "frac_step": round(bytes_per_unit * units_per_step / step_s / 1e9 / HBM_PEAK_GBPS, 5),
+            "kernel": ("csdev::trim_kernel<.., MODE_SCAN> + <.., MODE_RESOLVE> (one launch of each per step, one stream)"
+                       if args.serial else
+                       "csdev::trim_kernel<.., MODE_SCAN> (dominant; the step's <.., MODE_RESOLVE> launch runs on the "
+                       "resolve stream under the next step's scan kernel)"),
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
             "kernel_ms_last_step": {"scan": round(split_ms[0], 4), "resolve": round(split_ms[1], 4)},
             "bytes_per_unit": bytes_per_unit,
@@ -286,7 +307,7 @@ def main():
     if valu_insts:
         # the bound that governs: VALU issue slots.  achieved / peak in wave-instructions per second.
         peak = N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_INSTR
-        ach = valu_insts / avg_kernel_s
+        ach = valu_insts / (avg_kernel_s if args.serial else step_s)  # both kernels' instructions per step
         result["roofline_valu"] = {
             "bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
             "unit": "G wave-instr/s", "frac": round(ach / peak, 4),

@@ -15,7 +15,7 @@ LIB_PATH = Path(__file__).with_name("libcutseq_hip.so")
 
 EXPORTS = (
     "cs_abi_version", "cs_last_error", "cs_device_count", "cs_plan_create", "cs_plan_destroy", "cs_plan_set_demux",
-    "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_batch", "cs_sync",
+    "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_device_pipelined", "cs_join", "cs_trim_batch", "cs_sync",
     "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
     "cs_free_device", "cs_copy_to_device", "cs_copy_to_host",
 )
@@ -65,6 +65,10 @@ def load() -> C.CDLL:
     L.cs_engine_destroy.argtypes = [vp]
     L.cs_trim_device.restype = i32
     L.cs_trim_device.argtypes = [vp, vp, C.POINTER(abi.cs_reads), C.POINTER(abi.cs_reads), u32, u32]
+    L.cs_trim_device_pipelined.restype = i32
+    L.cs_trim_device_pipelined.argtypes = [vp, vp, C.POINTER(abi.cs_reads), C.POINTER(abi.cs_reads), u32, u32]
+    L.cs_join.restype = i32
+    L.cs_join.argtypes = [vp, vp]
     L.cs_trim_batch.restype = i32
     L.cs_trim_batch.argtypes = [vp, u32, C.POINTER(abi.cs_reads), C.POINTER(abi.cs_reads), u32, u32]
     L.cs_sync.restype = i32

@@ -51,6 +51,20 @@ struct Slot {
   bool busy = false;
 };
 
+// Everything one call keeps in flight: tile hand-out / queue counters, the queue of deferred reads and the
+// events around the two kernels.  Calls take the lanes in turn; a call first makes its stream wait for the
+// lane's previous user, so calls on different streams (and the pipelined form) never share live state.
+struct Lane {
+  uint32_t *d_counters = nullptr;
+  void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
+  uint32_t defer_capacity = 0;            // records per mate
+  hipEvent_t scanned = nullptr;           // scan kernel finished (what the resolve stream waits for)
+  hipEvent_t done = nullptr;              // resolve kernel finished
+  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_res = nullptr, ev_stop = nullptr;  // timing
+  bool used = false, timed = false;
+};
+constexpr int kLanes = 3;
+
 }  // namespace
 
 struct cs_plan {
@@ -84,10 +98,11 @@ struct cs_engine {
   int device = -1;
   hipStream_t stream = nullptr;
   int plan_slot = -1;  // index into the device's __constant__ plan table
+  hipStream_t resolve_stream = nullptr;  // pipelined calls: resolve kernel (and the slot's D2H) run here
   unsigned long long *d_stats = nullptr;
-  uint32_t *d_tile_counter = nullptr;
-  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;
-  bool timed = false;
+  Lane lanes[kLanes];
+  int next_lane = 0;
+  Lane *last_lane = nullptr;
   uint32_t max_reads = 0, max_stride = 0;
   bool paired = false;
   bool coded = false;
@@ -98,11 +113,10 @@ struct cs_engine {
   uint32_t waves_per_simd[2] = {4, 4};  // scan / resolve kernel, from their register counts
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds[2] = {0, 0};
-  void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
   std::vector<void *> d_tables;           // device copies of the CS_OP_DEMUX tables
-  uint32_t defer_capacity = 0;            // records per mate
   // tuning knobs, read once from the environment when the engine is created
   uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 1;  // batch knob: see trim_kernel (resolve)
+  uint32_t knob_resolve_waves = 4;  // pipelined calls: resolve waves per CU
   bool knob_units = false;
   uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 75;
 };
@@ -225,8 +239,11 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   return CS_OK;
 }
 
-int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
-           uint32_t stride, bool time_it) {
+// Scan kernel on `stream`, resolve kernel on `rstream` behind it (the same stream, or the engine's
+// resolve stream for the pipelined form: the next call's scan kernel then runs beside this call's resolve
+// kernel, whose few latency-bound waves fit into what the scan kernel leaves idle).
+int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_reads *r1, const cs_reads *r2,
+           uint32_t n_reads, uint32_t stride, bool time_it) {
   Geometry g[2];
   for (int mode = 0; mode < 2; ++mode) {
     int rc = geometry_for(eng, stride, mode, g[mode]);
@@ -248,27 +265,30 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     a.mate[m].cap2 = rr[m]->cap2;
     a.mate[m].bc = rr[m]->bc;
   }
+  Lane &ln = eng->lanes[eng->next_lane];
+  eng->next_lane = (eng->next_lane + 1) % kLanes;
+  if (ln.used) HIP_TRY(hipStreamWaitEvent(stream, ln.done, 0));  // the lane's previous call, on whatever stream it ran
   // queue of deferred reads: a read is deferred at most once by the scan kernel, so n_reads records per
   // mate always suffice (32 bytes each; typically a few per cent are used)
-  if (n_reads > eng->defer_capacity) {
-    HIP_TRY(hipStreamSynchronize(stream));  // an earlier launch may still be reading the old queue
+  if (n_reads > ln.defer_capacity) {
+    if (ln.used) HIP_TRY(hipEventSynchronize(ln.done));  // an earlier launch may still be reading the old queue
     for (int m = 0; m < 2; ++m) {
-      if (eng->d_defer[m]) (void)hipFree(eng->d_defer[m]);
-      eng->d_defer[m] = nullptr;
+      if (ln.d_defer[m]) (void)hipFree(ln.d_defer[m]);
+      ln.d_defer[m] = nullptr;
     }
-    eng->defer_capacity = 0;
+    ln.defer_capacity = 0;
     const uint32_t cap = n_reads + n_reads / 8 + 1024;
-    for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) HIP_TRY(hipMalloc(&eng->d_defer[m], (size_t)cap * kDeferRecordBytes));
-    eng->defer_capacity = cap;
+    for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) HIP_TRY(hipMalloc(&ln.d_defer[m], (size_t)cap * kDeferRecordBytes));
+    ln.defer_capacity = cap;
   }
-  a.defer[0] = reinterpret_cast<uint4 *>(eng->d_defer[0]);
-  a.defer[1] = reinterpret_cast<uint4 *>(eng->d_defer[1]);
-  a.defer_count = eng->d_tile_counter + kTileCounterDwords;
+  a.defer[0] = reinterpret_cast<uint4 *>(ln.d_defer[0]);
+  a.defer[1] = reinterpret_cast<uint4 *>(ln.d_defer[1]);
+  a.defer_count = ln.d_counters + kTileCounterDwords;
   a.stats = eng->d_stats;
   a.n_reads = n_reads;
   a.stride_dw = stride / 4;
   a.plan_slot = (uint32_t)eng->plan_slot;
-  a.tile_counter = eng->d_tile_counter;
+  a.tile_counter = ln.d_counters;
   a.n_table_ops = eng->n_table_ops;
   a.batch_knob = eng->knob_batch;
   for (int mode = 0; mode < 2; ++mode)
@@ -285,6 +305,9 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     if (per_cu > wave_cap) per_cu = wave_cap;
     if (per_cu < 1) per_cu = 1;
     // scan kernel: 2x the resident set, late blocks even out the tail; resolve kernel: the resident set
+    // pipelined resolve kernel: it runs beside the next call's scan kernel -- one wave per SIMD (its 128
+    // VGPRs are what four scan waves leave free), the scan kernel keeps the rest of the machine
+    if (mode == csdev::MODE_RESOLVE && rstream != stream && per_cu > eng->knob_resolve_waves) per_cu = eng->knob_resolve_waves;
     uint32_t resident = (uint32_t)eng->n_cus * per_cu * (mode == csdev::MODE_SCAN ? 2u : 1u);
     gx[mode] = resident / mates;
     if (mode == csdev::MODE_SCAN && eng->knob_grid_x) gx[mode] = eng->knob_grid_x;
@@ -304,21 +327,29 @@ int launch(cs_engine *eng, hipStream_t stream, const cs_reads *r1, const cs_read
     big_pct = eng->knob_big_pct;
   }
   a.big_tiles = (uint32_t)((uint64_t)n_tiles * big_pct / 100) & ~((1u << a.big_shift) - 1u);
-  HIP_TRY(hipMemsetAsync(eng->d_tile_counter, 0, kTileCounterBytes, stream));
-  if (time_it) HIP_TRY(hipEventRecord(eng->ev_start, stream));
+  // (the lane's counters are zero: cleared at creation and again behind every resolve kernel, off the scan stream)
+  if (time_it) HIP_TRY(hipEventRecord(ln.ev_start, stream));
   for (int mode = 0; mode < 2; ++mode) {
     a.lds_stride_dw = g[mode].lds_stride_dw;
     a.col_dwords = g[mode].col_dwords;
     void *kargs[] = {&a};
+    hipStream_t st = mode == csdev::MODE_SCAN ? stream : rstream;
+    if (mode == csdev::MODE_RESOLVE && rstream != stream) {
+      HIP_TRY(hipEventRecord(ln.scanned, stream));
+      HIP_TRY(hipStreamWaitEvent(rstream, ln.scanned, 0));
+    }
+    if (time_it && mode == csdev::MODE_RESOLVE) HIP_TRY(hipEventRecord(ln.ev_res, rstream));
     HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
-                            g[mode].lds_bytes, stream));
+                            g[mode].lds_bytes, st));
     HIP_TRY(hipGetLastError());
-    if (time_it && mode == csdev::MODE_SCAN) HIP_TRY(hipEventRecord(eng->ev_mid, stream));
+    if (time_it && mode == csdev::MODE_SCAN) HIP_TRY(hipEventRecord(ln.ev_mid, stream));
   }
-  if (time_it) {
-    HIP_TRY(hipEventRecord(eng->ev_stop, stream));
-    eng->timed = true;
-  }
+  if (time_it) HIP_TRY(hipEventRecord(ln.ev_stop, rstream));
+  HIP_TRY(hipMemsetAsync(ln.d_counters, 0, kTileCounterBytes, rstream));  // ready for the lane's next call
+  HIP_TRY(hipEventRecord(ln.done, rstream));
+  ln.used = true;
+  ln.timed = time_it;
+  eng->last_lane = &ln;
   return CS_OK;
 }
 
@@ -416,13 +447,16 @@ void cs_engine_destroy(cs_engine *eng) {
   }
   if (eng->plan_slot >= 0) release_plan_slot(eng->device, eng->plan_slot);
   if (eng->d_stats) (void)hipFree(eng->d_stats);
-  if (eng->d_tile_counter) (void)hipFree(eng->d_tile_counter);
-  for (int m = 0; m < 2; ++m)
-    if (eng->d_defer[m]) (void)hipFree(eng->d_defer[m]);
+  for (Lane &ln : eng->lanes) {
+    if (ln.used) (void)hipEventSynchronize(ln.done);
+    if (ln.d_counters) (void)hipFree(ln.d_counters);
+    for (int m = 0; m < 2; ++m)
+      if (ln.d_defer[m]) (void)hipFree(ln.d_defer[m]);
+    for (hipEvent_t ev : {ln.scanned, ln.done, ln.ev_start, ln.ev_mid, ln.ev_res, ln.ev_stop})
+      if (ev) (void)hipEventDestroy(ev);
+  }
   for (void *t : eng->d_tables) (void)hipFree(t);
-  if (eng->ev_start) (void)hipEventDestroy(eng->ev_start);
-  if (eng->ev_mid) (void)hipEventDestroy(eng->ev_mid);
-  if (eng->ev_stop) (void)hipEventDestroy(eng->ev_stop);
+  if (eng->resolve_stream) (void)hipStreamDestroy(eng->resolve_stream);
   if (eng->stream) (void)hipStreamDestroy(eng->stream);
   delete eng;
 }
@@ -479,9 +513,17 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   } while (0)
   ENG_TRY(hipSetDevice(device));
   ENG_TRY(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
-  ENG_TRY(hipEventCreate(&eng->ev_start));
-  ENG_TRY(hipEventCreate(&eng->ev_mid));
-  ENG_TRY(hipEventCreate(&eng->ev_stop));
+  ENG_TRY(hipStreamCreateWithFlags(&eng->resolve_stream, hipStreamNonBlocking));
+  for (Lane &ln : eng->lanes) {
+    ENG_TRY(hipMalloc(&ln.d_counters, kTileCounterBytes));
+    ENG_TRY(hipMemset(ln.d_counters, 0, kTileCounterBytes));
+    ENG_TRY(hipEventCreateWithFlags(&ln.scanned, hipEventDisableTiming));
+    ENG_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+    ENG_TRY(hipEventCreate(&ln.ev_start));
+    ENG_TRY(hipEventCreate(&ln.ev_mid));
+    ENG_TRY(hipEventCreate(&ln.ev_res));
+    ENG_TRY(hipEventCreate(&ln.ev_stop));
+  }
   eng->plan_slot = acquire_plan_slot(device);
   if (eng->plan_slot < 0) {
     fail(CS_ERR_STATE, "more than %d live engines on device %d", csdev::kMaxPlanSlots, device);
@@ -512,7 +554,6 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   }
   ENG_TRY(hipMalloc(&eng->d_stats, 2 * sizeof(cs_stats)));
   ENG_TRY(hipMemset(eng->d_stats, 0, 2 * sizeof(cs_stats)));
-  ENG_TRY(hipMalloc(&eng->d_tile_counter, kTileCounterBytes));
   eng->slots.resize(n_slots);
   const size_t bytes = (size_t)max_reads * max_stride;
   for (Slot &s : eng->slots) {
@@ -541,6 +582,10 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     if (v >= 1024 && v <= 32768) eng->knob_col_bytes = (uint32_t)v;
   }
   if (const char *env = getenv("CUTSEQ_BATCH_KNOB")) eng->knob_batch = (uint32_t)atol(env);
+  if (const char *env = getenv("CUTSEQ_RESOLVE_WAVES")) {
+    const long v = atol(env);
+    if (v >= 1 && v <= 16) eng->knob_resolve_waves = (uint32_t)v;
+  }
   if (const char *env = getenv("CUTSEQ_GRID_X")) {
     const long v = atol(env);
     if (v > 0) eng->knob_grid_x = (uint32_t)v;
@@ -563,7 +608,26 @@ int cs_trim_device(cs_engine *eng, void *stream, const cs_reads *r1, const cs_re
   if (!eng || !r1) return fail(CS_ERR_ARG, "null engine or reads");
   HIP_TRY(hipSetDevice(eng->device));
   hipStream_t st = stream ? (hipStream_t)stream : eng->stream;
-  return launch(eng, st, r1, r2, n_reads, stride, true);
+  return launch(eng, st, st, r1, r2, n_reads, stride, true);
+}
+
+int cs_trim_device_pipelined(cs_engine *eng, void *stream, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
+                             uint32_t stride) {
+  if (!eng || !r1) return fail(CS_ERR_ARG, "null engine or reads");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t st = stream ? (hipStream_t)stream : eng->stream;
+  return launch(eng, st, eng->resolve_stream, r1, r2, n_reads, stride, true);
+}
+
+int cs_join(cs_engine *eng, void *stream) {
+  if (!eng) return fail(CS_ERR_ARG, "null engine");
+  HIP_TRY(hipSetDevice(eng->device));
+  hipStream_t st = stream ? (hipStream_t)stream : eng->stream;
+  // every lane's last resolve kernel (the resolve stream is in order, but joined calls on other streams
+  // record their `done` elsewhere)
+  for (Lane &ln : eng->lanes)
+    if (ln.used) HIP_TRY(hipStreamWaitEvent(st, ln.done, 0));
+  return CS_OK;
 }
 
 int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_reads *r2, uint32_t n_reads,
@@ -591,15 +655,18 @@ int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_re
     dev[m].cap2 = (m == 0 && rr[m]->cap2) ? s.d_cap2 : nullptr;
     dev[m].bc = rr[m]->bc ? s.d_bc[m] : nullptr;
   }
-  int rc = launch(eng, eng->stream, &dev[0], r2 ? &dev[1] : nullptr, n_reads, stride, false);
+  // H2D and scan kernel on the engine stream, resolve kernel and D2H on the resolve stream: the next slot's
+  // copies and scan kernel overlap this slot's resolve kernel and write-back
+  hipStream_t rs = eng->resolve_stream;
+  int rc = launch(eng, eng->stream, rs, &dev[0], r2 ? &dev[1] : nullptr, n_reads, stride, false);
   if (rc) return rc;
   for (int m = 0; m < (r2 ? 2 : 1); ++m) {
-    HIP_TRY(hipMemcpyAsync(rr[m]->out, s.d_out[m], (size_t)n_reads * sizeof(cs_result), hipMemcpyDeviceToHost, eng->stream));
+    HIP_TRY(hipMemcpyAsync(rr[m]->out, s.d_out[m], (size_t)n_reads * sizeof(cs_result), hipMemcpyDeviceToHost, rs));
     if (m == 0 && rr[m]->cap2)
-      HIP_TRY(hipMemcpyAsync(rr[m]->cap2, s.d_cap2, (size_t)n_reads * sizeof(cs_cap2), hipMemcpyDeviceToHost, eng->stream));
-    if (rr[m]->bc) HIP_TRY(hipMemcpyAsync(rr[m]->bc, s.d_bc[m], (size_t)n_reads, hipMemcpyDeviceToHost, eng->stream));
+      HIP_TRY(hipMemcpyAsync(rr[m]->cap2, s.d_cap2, (size_t)n_reads * sizeof(cs_cap2), hipMemcpyDeviceToHost, rs));
+    if (rr[m]->bc) HIP_TRY(hipMemcpyAsync(rr[m]->bc, s.d_bc[m], (size_t)n_reads, hipMemcpyDeviceToHost, rs));
   }
-  HIP_TRY(hipEventRecord(s.done, eng->stream));
+  HIP_TRY(hipEventRecord(s.done, rs));
   s.busy = true;
   return CS_OK;
 }
@@ -618,7 +685,9 @@ int cs_sync(cs_engine *eng, uint32_t slot) {
 int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset) {
   if (!eng || !stats) return fail(CS_ERR_ARG, "null argument");
   HIP_TRY(hipSetDevice(eng->device));
-  // the engine's own stream; launches on a caller's stream (cs_trim_device) are the caller's to order
+  // behind every launch this engine has issued, on whatever stream
+  for (Lane &ln : eng->lanes)
+    if (ln.used) HIP_TRY(hipStreamWaitEvent(eng->stream, ln.done, 0));
   HIP_TRY(hipMemcpyAsync(stats, eng->d_stats, 2 * sizeof(cs_stats), hipMemcpyDeviceToHost, eng->stream));
   if (reset) HIP_TRY(hipMemsetAsync(eng->d_stats, 0, 2 * sizeof(cs_stats), eng->stream));
   HIP_TRY(hipStreamSynchronize(eng->stream));
@@ -627,20 +696,21 @@ int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset) {
 
 int cs_last_kernel_ms(cs_engine *eng, float *ms) {
   if (!eng || !ms) return fail(CS_ERR_ARG, "null argument");
-  if (!eng->timed) return fail(CS_ERR_STATE, "no timed launch yet");
-  HIP_TRY(hipSetDevice(eng->device));
-  HIP_TRY(hipEventSynchronize(eng->ev_stop));
-  HIP_TRY(hipEventElapsedTime(ms, eng->ev_start, eng->ev_stop));
+  float split[2];
+  int rc = cs_last_kernel_split_ms(eng, split);
+  if (rc) return rc;
+  *ms = split[0] + split[1];
   return CS_OK;
 }
 
 int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]) {
   if (!eng || !ms) return fail(CS_ERR_ARG, "null argument");
-  if (!eng->timed) return fail(CS_ERR_STATE, "no timed launch yet");
+  const Lane *ln = eng->last_lane;
+  if (!ln || !ln->timed) return fail(CS_ERR_STATE, "no timed launch yet");
   HIP_TRY(hipSetDevice(eng->device));
-  HIP_TRY(hipEventSynchronize(eng->ev_stop));
-  HIP_TRY(hipEventElapsedTime(&ms[0], eng->ev_start, eng->ev_mid));
-  HIP_TRY(hipEventElapsedTime(&ms[1], eng->ev_mid, eng->ev_stop));
+  HIP_TRY(hipEventSynchronize(ln->ev_stop));
+  HIP_TRY(hipEventElapsedTime(&ms[0], ln->ev_start, ln->ev_mid));
+  HIP_TRY(hipEventElapsedTime(&ms[1], ln->ev_res, ln->ev_stop));
   return CS_OK;
 }
 

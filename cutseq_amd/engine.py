@@ -126,9 +126,15 @@ class TrimEngine:
 
     # -- device-pointer path (inputs resident in HBM) --------------------------------------
     def trim_device(self, r1: abi.cs_reads, r2: Optional[abi.cs_reads], n_reads: int, stride: int,
-                    stream: Optional[int] = None):
-        capi.check(self.L.cs_trim_device(self._eng_h, stream, C.byref(r1), C.byref(r2) if r2 is not None else None,
-                                         n_reads, stride))
+                    stream: Optional[int] = None, pipelined: bool = False):
+        """Two kernel launches on ``stream``.  ``pipelined``: the resolve kernel goes to the engine's resolve stream
+        (the next call's scan kernel overlaps it); results are complete only after ``join(stream)``."""
+        fn = self.L.cs_trim_device_pipelined if pipelined else self.L.cs_trim_device
+        capi.check(fn(self._eng_h, stream, C.byref(r1), C.byref(r2) if r2 is not None else None, n_reads, stride))
+
+    def join(self, stream: Optional[int] = None):
+        """Make ``stream`` wait for every resolve kernel issued so far (pipelined calls)."""
+        capi.check(self.L.cs_join(self._eng_h, stream))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

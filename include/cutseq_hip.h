@@ -212,27 +212,38 @@ void cs_engine_destroy(cs_engine *eng);
  * (staging, bit-parallel filters, closed forms, cuts, quality trimming; reads that need the exact DP go
  * to a queue in HBM) and the resolve kernel (strip DP on that queue, then the rest of those reads'
  * chains) -- replacing the per-read modifier loop inside runner.run(pipeline, ...), run.py:473,794.
- * `stream` is a hipStream_t (NULL = the engine's own stream); asynchronous.
- * r2 == NULL for single-end.  An engine's launches must be ordered with respect to each other
- * (one stream at a time, or event dependencies between streams): they share the engine's tile
- * counters and statistics block.  Use one engine per concurrent stream. */
+ * `stream` is a hipStream_t (NULL = the engine's own stream); asynchronous: the results are complete
+ * in `stream` order.  r2 == NULL for single-end.  Calls may come on different streams: each call takes
+ * one of the engine's lanes (hand-out counters, queue) and first waits for that lane's previous user. */
 int cs_trim_device(cs_engine *eng, void *stream, const cs_reads *r1, const cs_reads *r2,
                    uint32_t n_reads, uint32_t stride);
 
-/* Same path for host buffers (pinned via cs_alloc_pinned for true overlap):
- * hipMemcpyAsync H2D -> kernel -> hipMemcpyAsync D2H on the engine stream, using
- * staging slot `slot`; returns immediately, cs_sync(eng, slot) waits for the results. */
+/* The same two launches, pipelined across calls: the scan kernel runs on `stream`, the resolve kernel on
+ * the engine's resolve stream behind it, so the NEXT call's scan kernel overlaps THIS call's resolve
+ * kernel (a few latency-bound waves that fit beside the scan kernel's).  The results of a pipelined call
+ * are complete in `stream` order only after cs_join(eng, stream); keep the result arrays of up to three
+ * calls apart (a call waits for the call three before it).  This is how a runner keeps batches in flight
+ * (make_runner(cores=N), run.py:436,753) and what bench.py times. */
+int cs_trim_device_pipelined(cs_engine *eng, void *stream, const cs_reads *r1, const cs_reads *r2,
+                             uint32_t n_reads, uint32_t stride);
+/* makes `stream` (NULL = the engine's own) wait for every resolve kernel issued so far */
+int cs_join(cs_engine *eng, void *stream);
+
+/* Same path for host buffers (pinned via cs_alloc_pinned for true overlap), pipelined the same way:
+ * hipMemcpyAsync H2D -> scan kernel on the engine stream, resolve kernel -> hipMemcpyAsync D2H on the
+ * resolve stream, using staging slot `slot`; returns immediately, cs_sync(eng, slot) waits for the
+ * results.  With two slots in flight one slot's upload and scan overlap the other's resolve and download. */
 int cs_trim_batch(cs_engine *eng, uint32_t slot, const cs_reads *r1, const cs_reads *r2,
                   uint32_t n_reads, uint32_t stride);
 int cs_sync(cs_engine *eng, uint32_t slot);
 
 /* Device-side counters (counterpart of cutadapt's Statistics, run.py:473,794).
- * stats[0] = mate 1, stats[1] = mate 2.  Synchronises the engine's own stream (cs_trim_batch); work a
- * caller launched on a stream of its own (cs_trim_device) is the caller's to synchronise first. */
+ * stats[0] = mate 1, stats[1] = mate 2.  Ordered behind every launch the engine has issued so far (on
+ * any stream) and synchronous. */
 int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset);
 
-/* Timing of the last cs_trim_device launch on its stream, measured with HIP events
- * recorded around the two kernels (ms).  Synchronises on the stop event. */
+/* Timing of the last cs_trim_device / cs_trim_device_pipelined call, measured with HIP events recorded
+ * around each kernel on the stream it ran on (ms, the two kernels added).  Synchronises on the stop event. */
 int cs_last_kernel_ms(cs_engine *eng, float *ms);
 /* the same launch split into its two kernels: ms[0] = scan kernel, ms[1] = resolve kernel */
 int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]);

@@ -1,0 +1,93 @@
+"""The device-pointer entry points (cs_trim_device, cs_trim_device_pipelined + cs_join) against the oracle.
+
+Batches already resident in HBM, as bench.py drives them: joined calls, pipelined calls on one stream with
+one set of result arrays per call in flight (more calls than the engine has lanes, so lanes get reused),
+and joined calls alternating between two streams on one engine.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from cutseq_amd import abi, plan as planmod, synth
+from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
+from cutseq_amd.engine import TrimEngine
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def takara_plan():
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    return planmod.compile_paired(BarcodeConfig(BUILDIN_ADAPTERS["TAKARAV3"]), st)
+
+
+class Resident:
+    """One synthetic batch on the device + its own result arrays."""
+
+    def __init__(self, batch, dev):
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.batch = batch
+        self.t = [up(batch.seq1), up(batch.qual1), up(batch.len1.view(np.int16)),
+                  up(batch.seq2), up(batch.qual2), up(batch.len2.view(np.int16))]
+        self.out1 = torch.zeros((batch.n, 8), dtype=torch.uint8, device=dev)
+        self.out2 = torch.zeros((batch.n, 8), dtype=torch.uint8, device=dev)
+        p = [x.data_ptr() for x in self.t]
+        self.r1 = abi.cs_reads(p[0], p[1], p[2], self.out1.data_ptr(), None, None)
+        self.r2 = abi.cs_reads(p[3], p[4], p[5], self.out2.data_ptr(), None, None)
+
+    def results(self):
+        return (self.out1.cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1),
+                self.out2.cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1))
+
+
+def expect(tp, batch):
+    (o1, _, st1), (o2, _, st2) = util.oracle_run(tp, batch, threads=8)
+    return o1, o2, st1, st2
+
+
+@pytest.mark.parametrize("form", ["joined", "pipelined", "two_streams"])
+def test_resident_batches(form):
+    dev = torch.device("cuda:0")
+    tp = takara_plan()
+    # different sizes: the queue of a reused lane has to grow, the last batch is a ragged tile
+    sizes = [30_000, 50_000, 20_001, 64, 70_000, 1, 40_000]
+    batches = [synth.generate_pairs(n, 150, first_index=1000 * i) for i, n in enumerate(sizes)]
+    res = [Resident(b, dev) for b in batches]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    handles = [C.c_void_p(s.cuda_stream) for s in streams]
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        for i, r in enumerate(res):
+            if form == "joined":
+                eng.trim_device(r.r1, r.r2, r.batch.n, r.batch.stride, stream=handles[0])
+            elif form == "pipelined":
+                eng.trim_device(r.r1, r.r2, r.batch.n, r.batch.stride, stream=handles[0], pipelined=True)
+            else:
+                eng.trim_device(r.r1, r.r2, r.batch.n, r.batch.stride, stream=handles[i % 2])
+        if form == "pipelined":
+            eng.join(handles[0])
+            streams[0].synchronize()  # results are complete in stream order behind the join
+        else:
+            for s in streams:
+                s.synchronize()
+        gst1, gst2 = eng.stats()
+        scan_ms, resolve_ms = eng.last_kernel_split_ms()
+        assert scan_ms > 0 and resolve_ms > 0
+    tot = {}
+    for r in res:
+        o1, o2, st1, st2 = expect(tp, r.batch)
+        g1, g2 = r.results()
+        assert (g1 == o1).all() and (g2 == o2).all()
+        for mate, st in ((1, st1), (2, st2)):
+            for k, v in st.as_dict().items():
+                if k == "n_exact_dp":
+                    continue
+                key = (mate, k)
+                tot[key] = (np.asarray(tot[key]) + np.asarray(v)).tolist() if key in tot else v
+    for mate, st in ((1, gst1), (2, gst2)):
+        for k, v in st.as_dict().items():
+            if k != "n_exact_dp":
+                assert np.array_equal(np.asarray(v), np.asarray(tot[(mate, k)])), (mate, k)
