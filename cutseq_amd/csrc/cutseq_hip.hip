@@ -60,8 +60,9 @@ struct Lane {
   uint32_t defer_capacity = 0;            // records per mate
   hipEvent_t scanned = nullptr;           // scan kernel finished (what the resolve stream waits for)
   hipEvent_t done = nullptr;              // resolve kernel finished
-  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_res = nullptr, ev_stop = nullptr;  // timing
+  hipEvent_t ev_start = nullptr, ev_mid = nullptr, ev_stop = nullptr;  // timing: scan = start..mid, resolve = mid..stop
   bool used = false, timed = false;
+  bool unharvested = false;  // the timing events of the lane's last call have not been added to the totals yet
 };
 constexpr int kLanes = 3;
 
@@ -103,6 +104,8 @@ struct cs_engine {
   Lane lanes[kLanes];
   int next_lane = 0;
   Lane *last_lane = nullptr;
+  uint32_t timed_calls = 0;           // since the last reset of the totals
+  double kernel_ms_total[2] = {0, 0};  // scan / resolve kernel, HIP-event durations of those calls
   uint32_t max_reads = 0, max_stride = 0;
   bool paired = false;
   bool coded = false;
@@ -239,6 +242,20 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   return CS_OK;
 }
 
+// Adds the event-measured kernel durations of a lane's last call to the engine's totals (waits for that call).
+int harvest(cs_engine *eng, Lane &ln) {
+  if (!ln.unharvested) return CS_OK;
+  float a = 0, b = 0;
+  HIP_TRY(hipEventSynchronize(ln.ev_stop));
+  HIP_TRY(hipEventElapsedTime(&a, ln.ev_start, ln.ev_mid));
+  HIP_TRY(hipEventElapsedTime(&b, ln.ev_mid, ln.ev_stop));  // from "scan kernel done": includes the hand-over to the resolve stream
+  eng->kernel_ms_total[0] += a;
+  eng->kernel_ms_total[1] += b;
+  ++eng->timed_calls;
+  ln.unharvested = false;
+  return CS_OK;
+}
+
 // Scan kernel on `stream`, resolve kernel on `rstream` behind it (the same stream, or the engine's
 // resolve stream for the pipelined form: the next call's scan kernel then runs beside this call's resolve
 // kernel, whose few latency-bound waves fit into what the scan kernel leaves idle).
@@ -328,7 +345,11 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   }
   a.big_tiles = (uint32_t)((uint64_t)n_tiles * big_pct / 100) & ~((1u << a.big_shift) - 1u);
   // (the lane's counters are zero: cleared at creation and again behind every resolve kernel, off the scan stream)
-  if (time_it) HIP_TRY(hipEventRecord(ln.ev_start, stream));
+  if (time_it) {
+    int rc = harvest(eng, ln);  // the call three before this one: long finished
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ln.ev_start, stream));
+  }
   for (int mode = 0; mode < 2; ++mode) {
     a.lds_stride_dw = g[mode].lds_stride_dw;
     a.col_dwords = g[mode].col_dwords;
@@ -338,7 +359,6 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
       HIP_TRY(hipEventRecord(ln.scanned, stream));
       HIP_TRY(hipStreamWaitEvent(rstream, ln.scanned, 0));
     }
-    if (time_it && mode == csdev::MODE_RESOLVE) HIP_TRY(hipEventRecord(ln.ev_res, rstream));
     HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
                             g[mode].lds_bytes, st));
     HIP_TRY(hipGetLastError());
@@ -349,6 +369,7 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   HIP_TRY(hipEventRecord(ln.done, rstream));
   ln.used = true;
   ln.timed = time_it;
+  ln.unharvested = time_it;
   eng->last_lane = &ln;
   return CS_OK;
 }
@@ -452,7 +473,7 @@ void cs_engine_destroy(cs_engine *eng) {
     if (ln.d_counters) (void)hipFree(ln.d_counters);
     for (int m = 0; m < 2; ++m)
       if (ln.d_defer[m]) (void)hipFree(ln.d_defer[m]);
-    for (hipEvent_t ev : {ln.scanned, ln.done, ln.ev_start, ln.ev_mid, ln.ev_res, ln.ev_stop})
+    for (hipEvent_t ev : {ln.scanned, ln.done, ln.ev_start, ln.ev_mid, ln.ev_stop})
       if (ev) (void)hipEventDestroy(ev);
   }
   for (void *t : eng->d_tables) (void)hipFree(t);
@@ -521,7 +542,6 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     ENG_TRY(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
     ENG_TRY(hipEventCreate(&ln.ev_start));
     ENG_TRY(hipEventCreate(&ln.ev_mid));
-    ENG_TRY(hipEventCreate(&ln.ev_res));
     ENG_TRY(hipEventCreate(&ln.ev_stop));
   }
   eng->plan_slot = acquire_plan_slot(device);
@@ -710,7 +730,24 @@ int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]) {
   HIP_TRY(hipSetDevice(eng->device));
   HIP_TRY(hipEventSynchronize(ln->ev_stop));
   HIP_TRY(hipEventElapsedTime(&ms[0], ln->ev_start, ln->ev_mid));
-  HIP_TRY(hipEventElapsedTime(&ms[1], ln->ev_res, ln->ev_stop));
+  HIP_TRY(hipEventElapsedTime(&ms[1], ln->ev_mid, ln->ev_stop));
+  return CS_OK;
+}
+
+int cs_kernel_time_totals(cs_engine *eng, uint32_t *calls, float ms[2], int reset) {
+  if (!eng || !calls || !ms) return fail(CS_ERR_ARG, "null argument");
+  HIP_TRY(hipSetDevice(eng->device));
+  for (Lane &ln : eng->lanes) {
+    int rc = harvest(eng, ln);
+    if (rc) return rc;
+  }
+  *calls = eng->timed_calls;
+  ms[0] = (float)eng->kernel_ms_total[0];
+  ms[1] = (float)eng->kernel_ms_total[1];
+  if (reset) {
+    eng->timed_calls = 0;
+    eng->kernel_ms_total[0] = eng->kernel_ms_total[1] = 0;
+  }
   return CS_OK;
 }
 

@@ -147,6 +147,12 @@ class TrimEngine:
         capi.check(self.L.cs_last_kernel_split_ms(self._eng_h, C.byref(ms)))
         return float(ms[0]), float(ms[1])
 
+    def kernel_time_totals(self, reset: bool = False) -> Tuple[int, float, float]:
+        """(timed calls, scan-kernel ms, resolve-kernel ms) summed over the ``trim_device`` calls since the last reset."""
+        calls, ms = C.c_uint32(), (C.c_float * 2)()
+        capi.check(self.L.cs_kernel_time_totals(self._eng_h, C.byref(calls), C.byref(ms), 1 if reset else 0))
+        return int(calls.value), float(ms[0]), float(ms[1])
+
     def stats(self, reset: bool = False) -> Tuple[abi.cs_stats, abi.cs_stats]:
         st = (abi.cs_stats * 2)()
         capi.check(self.L.cs_stats_fetch(self._eng_h, C.byref(st), 1 if reset else 0))

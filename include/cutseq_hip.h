@@ -247,6 +247,9 @@ int cs_stats_fetch(cs_engine *eng, cs_stats stats[2], int reset);
 int cs_last_kernel_ms(cs_engine *eng, float *ms);
 /* the same launch split into its two kernels: ms[0] = scan kernel, ms[1] = resolve kernel */
 int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]);
+/* Sums of those event-measured durations over every cs_trim_device / cs_trim_device_pipelined call since
+ * the last reset (*calls of them): the per-kernel averages bench.py reports.  Waits for the calls in flight. */
+int cs_kernel_time_totals(cs_engine *eng, uint32_t *calls, float ms[2], int reset);
 
 void *cs_alloc_pinned(size_t bytes);
 void cs_free_pinned(void *p);

@@ -54,6 +54,25 @@ def main():
         same = all(torch.equal(keep[0], keep[2 * e]) and torch.equal(keep[1], keep[2 * e + 1]) for e in range(n_eng))
         print("  results identical across engines:", same, flush=True)
         del engines
+    # the engine's own pipeline: one stream, resolve kernels on the engine's resolve stream (what bench.py times)
+    eng = TrimEngine(tp, device=0, slots=0)
+    st = torch.cuda.Stream(device=dev)
+    sh = C.c_void_p(st.cuda_stream)
+    sets = []
+    for _ in range(3):
+        o1 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+        o2 = torch.empty((n, 8), dtype=torch.uint8, device=dev)
+        sets.append((abi.cs_reads(d["seq1"].data_ptr(), d["qual1"].data_ptr(), d["len1"].data_ptr(), o1.data_ptr(), None, None),
+                     abi.cs_reads(d["seq2"].data_ptr(), d["qual2"].data_ptr(), d["len2"].data_ptr(), o2.data_ptr(), None, None), o1, o2))
+    for rep in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.trim_device(sets[i % 3][0], sets[i % 3][1], n, batch.stride, stream=sh, pipelined=True)
+        eng.join(sh)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        print(f"pipelined, one engine: {steps * n / dt / 1e6:.1f} M pairs/s  ({dt / steps * 1e3:.3f} ms/step)", flush=True)
 
 
 if __name__ == "__main__":
