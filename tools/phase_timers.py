@@ -51,6 +51,14 @@ r2 = abi.cs_reads(keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), ou
 st = planmod.CutadaptConfig()
 st.trim_polyA = True
 tp = planmod.compile_paired(BarcodeConfig(BUILDIN_ADAPTERS["TAKARAV3"]), st)
+VARIANT = os.environ.get("CS_PLAN", "full")  # full | only_5prime | only_3prime | no_5prime
+if VARIANT != "full":
+    A = planmod.AdapterOp
+    pred = {"only_5prime": lambda o: isinstance(o, A) and o.rightmost,
+            "only_3prime": lambda o: isinstance(o, A) and o.kind_name == "BackAdapter",
+            "no_5prime": lambda o: not (isinstance(o, A) and o.rightmost)}[VARIANT]
+    tp.r1.ops = [o for o in tp.r1.ops if pred(o)]
+    tp.r2.ops = [o for o in tp.r2.ops if pred(o)]
 eng = TrimEngine(tp, device=0, slots=0)
 eng.trim_device(r1, r2, n, batch.stride)
 torch.cuda.synchronize()
@@ -59,7 +67,7 @@ eng.trim_device(r1, r2, n, batch.stride)
 torch.cuda.synchronize()
 ms = eng.last_kernel_ms()
 stats = eng.stats()
-print(f"{n} pairs, both kernels {ms:.3f} ms (instrumented build), reporting: {'scan' if WHICH == '1' else 'resolve'} kernel")
+print(f"plan {VARIANT}: {n} pairs, both kernels {ms:.3f} ms (instrumented build), reporting: {'scan' if WHICH == '1' else 'resolve'} kernel")
 for mate, s in enumerate(stats):
     t = np.array([int(s.op_matched[16 + i]) for i in range(8)], dtype=np.float64) * 64
     tot = t.sum()
