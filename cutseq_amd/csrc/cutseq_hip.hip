@@ -179,7 +179,7 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
         out.filter_mode = csdev::FILTER_POLY_HEAD;
       else if (acgt && op.m <= 32)
         out.filter_mode = csdev::FILTER_MYERS32;
-      else if (acgt && op.m <= 64)
+      else if (acgt && op.m <= 64 && op.m + op.k <= 127)  // (scores of a column group travel as bytes below 128)
         out.filter_mode = csdev::FILTER_MYERS64;
       break;
     }
