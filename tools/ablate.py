@@ -44,6 +44,10 @@ variants = {
     "full": full(),
     "full_nofilter": full(use_filter=False),
     "no_polyA": full(polyA=False),
+    "no_qtrim": keep(full(), lambda o: not isinstance(o, Q)),
+    "no_5prime": keep(full(), lambda o: not (isinstance(o, A) and o.rightmost)),
+    "no_3prime": keep(full(), lambda o: not (isinstance(o, A) and o.kind_name == "BackAdapter")),
+    "no_cuts": keep(full(), lambda o: not isinstance(o, Cu)),
     "only_5prime": keep(full(), lambda o: isinstance(o, A) and o.rightmost),
     "only_3prime": keep(full(), lambda o: isinstance(o, A) and o.kind_name == "BackAdapter"),
     "only_poly": keep(full(), lambda o: isinstance(o, A) and o.kind_name.startswith("NonInternal")),
