@@ -534,7 +534,14 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   } while (0)
   ENG_TRY(hipSetDevice(device));
   ENG_TRY(hipStreamCreateWithFlags(&eng->stream, hipStreamNonBlocking));
-  ENG_TRY(hipStreamCreateWithFlags(&eng->resolve_stream, hipStreamNonBlocking));
+  {
+    // the resolve stream outranks the scan stream: when one batch's resolve kernel and the next batch's scan
+    // kernel become ready together, the resolve kernel's few blocks are placed first (the scan kernel would
+    // fill every SIMD and leave them waiting until it ends)
+    int least = 0, greatest = 0;
+    ENG_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    ENG_TRY(hipStreamCreateWithPriority(&eng->resolve_stream, hipStreamNonBlocking, greatest));
+  }
   for (Lane &ln : eng->lanes) {
     ENG_TRY(hipMalloc(&ln.d_counters, kTileCounterBytes));
     ENG_TRY(hipMemset(ln.d_counters, 0, kTileCounterBytes));
