@@ -429,6 +429,25 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
         for (int j = 0; j < d.op.m; ++j) d.op.seq[j] = (uint8_t)csdev::base_code(d.op.seq[j]);
         d.base_char = csdev::base_code(d.base_char);
       }
+  // the tables a block copies into LDS when it starts
+  static_assert(csdev::kFnibDwords == 6, "DevOp::fnib");
+  for (int m = 0; m < 2; ++m)
+    for (int i = 0; i < cnt[m]; ++i) {
+      csdev::DevOp &d = p->host.ops[m][i];
+      memset(d.eq_tab, 0, sizeof d.eq_tab);
+      memset(d.fnib, 0, sizeof d.fnib);
+      if (d.op.kind != CS_OP_ADAPTER) continue;
+      const int mm = d.op.m;
+      for (int ent = 0; ent < 4; ++ent) {
+        const int which = (ent == 0) ? 0 : (ent == 1) ? 1 : (ent == 2) ? 3 : 2;  // sel 2 = T, sel 3 = G
+        const uint64_t mask = d.peq[which];
+        d.eq_tab[ent * 2] = (uint32_t)mask;
+        d.eq_tab[ent * 2 + 1] = (mm >= 1 && mm <= 32) ? ((uint32_t)mask << (32 - mm)) : (uint32_t)(mask >> 32);
+      }
+      if (coded)
+        for (int idx = 0; idx < mm && idx < 32; ++idx)
+          d.fnib[idx >> 3] |= (uint32_t)((d.op.seq[d.op.reversed ? mm - 1 - idx : idx] >> 3) & 7u) << (4 * (idx & 7));
+    }
   *out = p;
   return CS_OK;
 }
