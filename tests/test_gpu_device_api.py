@@ -91,3 +91,35 @@ def test_resident_batches(form):
         for k, v in st.as_dict().items():
             if k != "n_exact_dp":
                 assert np.array_equal(np.asarray(v), np.asarray(tot[(mate, k)])), (mate, k)
+
+
+def test_single_end_pipelined_with_second_capture_and_timing_totals():
+    """Single-end scheme with a UMI on either side (second capture array), pipelined calls, and the per-kernel
+    time totals the bench reads: one entry per timed call, reset on request."""
+    dev = torch.device("cuda:0")
+    st = planmod.CutadaptConfig()
+    tp = planmod.compile_single(BarcodeConfig("ACACGACGCTCTTCCGATCTNNNNNN>NNNNAGATCGGAAGAGCACACGTC"), st)
+    assert tp.needs_cap2
+    batches = [synth.generate_pairs(n, 150, scheme="ACACGACGCTCTTCCGATCTNNNNNN>NNNNAGATCGGAAGAGCACACGTC", single_end=True,
+                                    first_index=77 * i) for i, n in enumerate([20_000, 33_333, 5])]
+    stream = torch.cuda.Stream(device=dev)
+    sh = C.c_void_p(stream.cuda_stream)
+    keep = []
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        assert eng.kernel_time_totals(reset=True)[0] == 0
+        for b in batches:
+            t = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (b.seq1, b.qual1, b.len1.view(np.int16))]
+            out = torch.zeros((b.n, 8), dtype=torch.uint8, device=dev)
+            cap2 = torch.zeros((b.n, 4), dtype=torch.uint8, device=dev)
+            keep.append((t, out, cap2))
+            r1 = abi.cs_reads(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr(), cap2.data_ptr(), None)
+            eng.trim_device(r1, None, b.n, b.stride, stream=sh, pipelined=True)
+        eng.join(sh)
+        stream.synchronize()
+        calls, scan_ms, resolve_ms = eng.kernel_time_totals(reset=True)
+        assert calls == len(batches) and scan_ms > 0 and resolve_ms > 0
+        assert eng.kernel_time_totals()[0] == 0
+    for b, (_, out, cap2) in zip(batches, keep):
+        (o1, ocap2, _), _m2 = util.oracle_run(tp, b, threads=8)
+        assert (out.cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1) == o1).all()
+        assert (cap2.cpu().numpy().view(abi.CAP2_DTYPE).reshape(-1) == ocap2).all()
