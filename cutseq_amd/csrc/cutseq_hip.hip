@@ -121,7 +121,7 @@ struct cs_engine {
   uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 1;  // batch knob: see trim_kernel (resolve)
   uint32_t knob_resolve_waves = 4;  // pipelined calls: resolve waves per CU
   bool knob_units = false;
-  uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 75;
+  uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 50;
 };
 
 namespace {
@@ -332,12 +332,13 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
     if (gx[mode] > n_tiles) gx[mode] = n_tiles;
   }
   // tile hand-out (see the kernel): big units, about a quarter of a block's share (at most 8 tiles), for
-  // the first 3/4 of the batch, single tiles for the rest.
+  // the first half of the batch, single tiles for the rest (the counter's answer is not waited for any more:
+  // small units cost nothing and even out the end of the kernel).
   a.static_units = gx[0] / 2 > 0 ? gx[0] / 2 : 1;  // the half of the grid that is resident from the start
   const uint32_t share = n_tiles / a.static_units;
   a.big_shift = share >= 32 ? 3 : share >= 16 ? 2 : 1;
   a.small_shift = 0;
-  uint32_t big_pct = 75;
+  uint32_t big_pct = 50;
   if (eng->knob_units) {
     a.big_shift = eng->knob_big_shift;
     a.small_shift = eng->knob_small_shift;
