@@ -284,7 +284,9 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   }
   Lane &ln = eng->lanes[eng->next_lane];
   eng->next_lane = (eng->next_lane + 1) % kLanes;
-  if (ln.used) HIP_TRY(hipStreamWaitEvent(stream, ln.done, 0));  // the lane's previous call, on whatever stream it ran
+  // the lane's previous call, on whatever stream it ran: as a rule it finished long ago (three calls back) and
+  // the stream is spared a marker
+  if (ln.used && hipEventQuery(ln.done) != hipSuccess) HIP_TRY(hipStreamWaitEvent(stream, ln.done, 0));
   // queue of deferred reads: a read is deferred at most once by the scan kernel, so n_reads records per
   // mate always suffice (32 bytes each; typically a few per cent are used)
   if (n_reads > ln.defer_capacity) {
@@ -357,8 +359,9 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
     void *kargs[] = {&a};
     hipStream_t st = mode == csdev::MODE_SCAN ? stream : rstream;
     if (mode == csdev::MODE_RESOLVE && rstream != stream) {
-      HIP_TRY(hipEventRecord(ln.scanned, stream));
-      HIP_TRY(hipStreamWaitEvent(rstream, ln.scanned, 0));
+      // (one marker on the scan stream serves the timing and the hand-over: ev_mid when the call is timed)
+      if (!time_it) HIP_TRY(hipEventRecord(ln.scanned, stream));
+      HIP_TRY(hipStreamWaitEvent(rstream, time_it ? ln.ev_mid : ln.scanned, 0));
     }
     HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
                             g[mode].lds_bytes, st));
