@@ -201,7 +201,91 @@ class GzipSource:
             yield from self._members(tail)
 
     # -- generic gzip: one libdeflate call per member ----------------------------------------------
+    def _inflate_member_at(self, pos: int, cap: int):
+        """One member that starts at ``pos`` -> (rc, bytes consumed, buffer, bytes produced); rc 0 = fine, 3 = does
+        not fit ``_MEMBER_CAP``, anything else = no gzip member starts here (or it is corrupt)."""
+        L, d = libdeflate(), _decompressor()
+        base = _view_address(memoryview(self.map))
+        n_in, n_out = C.c_size_t(), C.c_size_t()
+        out = self.take(cap)
+        while True:
+            rc = L.libdeflate_gzip_decompress_ex(d, base + pos, self.size - pos, out.ctypes.data, out.size, C.byref(n_in),
+                                                 C.byref(n_out))
+            if rc == 3 and out.size < _MEMBER_CAP:
+                self.give(out)
+                out = self.take(min(_MEMBER_CAP, 4 * out.size))
+                continue
+            break
+        if rc != 0:
+            self.give(out)
+            return rc, 0, None, 0
+        return 0, int(n_in.value), out, int(n_out.value)
+
     def _members(self, start: int = 0) -> Iterator[tuple]:
+        if self.pool is None:
+            yield from self._members_serial(start)
+        else:
+            yield from self._members_speculative(start)
+
+    def _members_speculative(self, start: int) -> Iterator[tuple]:
+        """Members inflate in parallel although their boundaries are only known once the member in front has been
+        inflated: every ``1f 8b 08`` with clean flag bits behind the current member is tried as a member start in
+        the pool; when the current member is done, the next one is usually finished or under way already.  A false
+        candidate fails in its header or a few blocks in and is thrown away; order and content are those of the
+        serial walk (the chain only ever follows ``start + bytes consumed``)."""
+        buf, n = self.map, self.size
+        window = 8  # candidates in flight beyond the current member
+        tasks = {}  # member start -> future of _inflate_member_at
+        cands = []  # ascending candidate starts behind the current member
+        scan_from = start + 1
+        cap = [32 << 20]  # output size to start with: the largest member seen so far
+
+        def submit(pos):
+            if pos not in tasks:
+                tasks[pos] = self.pool.submit(self._inflate_member_at, pos, cap[0])
+
+        def drop(pos):  # a candidate the chain walked past: give its buffer back when (if) it finishes
+            fut = tasks.pop(pos, None)
+            if fut is not None and not fut.cancel():
+                fut.add_done_callback(lambda f: f.exception() is None and f.result()[2] is not None and self.give(f.result()[2]))
+
+        head = start
+        try:
+            while head < n:
+                if buf[head] == 0 and not any(buf[head:min(n, head + (1 << 20))]):
+                    return  # zero padding after the last member (tar-style): done
+                submit(head)
+                while len(cands) < window and scan_from < n:
+                    p = buf.find(b"\x1f\x8b\x08", scan_from)
+                    if p < 0:
+                        scan_from = n
+                        break
+                    scan_from = p + 1
+                    if p + 18 <= n and (buf[p + 3] & 0xE0) == 0:
+                        cands.append(p)
+                for p in cands:
+                    submit(p)
+                rc, used, out, produced = tasks.pop(head).result()
+                if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
+                    for p in list(tasks):
+                        drop(p)
+                    yield from self._zlib_stream(head)
+                    return
+                if rc != 0:
+                    raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
+                cap[0] = max(cap[0], min(_MEMBER_CAP, 1 << max(produced - 1, 1).bit_length()))
+                yield out, produced
+                head += used
+                while cands and cands[0] <= head:
+                    p = cands.pop(0)
+                    if p < head:
+                        drop(p)
+                scan_from = max(scan_from, head + 1)
+        finally:
+            for p in list(tasks):
+                drop(p)
+
+    def _members_serial(self, start: int = 0) -> Iterator[tuple]:
         L, d = libdeflate(), _decompressor()
         buf, n = self.map, self.size
         base = _view_address(memoryview(buf))

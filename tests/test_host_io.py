@@ -396,6 +396,40 @@ def test_codec_truncated_and_corrupt_input(tmp_path):
     assert _inflate(empty) == b""
 
 
+def test_codec_members_inflate_ahead_of_their_boundaries(tmp_path):
+    """With a pool, members are tried at every gzip magic behind the current one before their true starts are
+    known.  Payloads full of false magics (stored blocks keep them verbatim), empty members, zero padding, a
+    corrupt member and a truncated tail must come out exactly as from the serial walk."""
+    import os
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+    from cutseq_amd import codec
+    rng = random.Random(11)
+    parts = []
+    for i in range(30):
+        noise = os.urandom(rng.randint(0, 120_000))  # incompressible: stored verbatim, magics and all
+        parts.append(noise + b"\x1f\x8b\x08\x00" * rng.randint(0, 6) + b"ACGT" * rng.randint(0, 20_000))
+    parts[7] = b""
+    blob = b"".join(gzip.compress(x, 1) for x in parts)
+    want = b"".join(parts)
+    good = tmp_path / "speculative.gz"
+    good.write_bytes(blob + b"\0" * 8192)
+    with ThreadPoolExecutor(6) as pool:
+        assert _inflate(good) == want
+        for _ in range(3):
+            assert _inflate(good, pool) == want
+        bad = bytearray(blob)
+        bad[len(bad) * 2 // 3] ^= 0x55
+        broken = tmp_path / "speculative_bad.gz"
+        broken.write_bytes(bytes(bad))
+        with pytest.raises(OSError):
+            _inflate(broken, pool)
+        cut = tmp_path / "speculative_cut.gz"
+        cut.write_bytes(blob[:-37])
+        with pytest.raises(OSError):
+            _inflate(cut, pool)
+
+
 def test_reader_takes_bgzf_and_multi_member_input(tmp_path):
     """read_chunks on BGZF / multi-member files yields the same records as on the plain text."""
     text, paths = _codec_files(tmp_path)
