@@ -232,6 +232,7 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   uint32_t words = kTileRows * g.lds_stride_dw + eng->n_table_ops * (csdev::kEqTableBytes / 4 + csdev::kFnibDwords) +
                    csdev::kStatWords +
                    96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
+  if (mode == csdev::MODE_SCAN) words += csdev::kRingRecords * 8;  // queue records waiting for their reservation
   if (mode == csdev::MODE_RESOLVE) {
     g.col_dwords = eng->col_dwords;
     if (eng->knob_col_bytes / 4 > g.col_dwords) g.col_dwords = eng->knob_col_bytes / 4;
