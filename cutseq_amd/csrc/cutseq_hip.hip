@@ -291,15 +291,20 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   // queue of deferred reads: a read is deferred at most once by the scan kernel, so n_reads records per
   // mate always suffice (32 bytes each; typically a few per cent are used)
   if (n_reads > ln.defer_capacity) {
-    if (ln.used) HIP_TRY(hipEventSynchronize(ln.done));  // an earlier launch may still be reading the old queue
-    for (int m = 0; m < 2; ++m) {
-      if (ln.d_defer[m]) (void)hipFree(ln.d_defer[m]);
-      ln.d_defer[m] = nullptr;
-    }
-    ln.defer_capacity = 0;
+    // every lane grows at once: the allocations (and their synchronisation) happen at the first call of a new
+    // batch size, not one lane at a time over the first calls
     const uint32_t cap = n_reads + n_reads / 8 + 1024;
-    for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) HIP_TRY(hipMalloc(&ln.d_defer[m], (size_t)cap * kDeferRecordBytes));
-    ln.defer_capacity = cap;
+    for (Lane &l : eng->lanes) {
+      if (cap <= l.defer_capacity) continue;
+      if (l.used) HIP_TRY(hipEventSynchronize(l.done));  // an earlier launch may still be reading the old queue
+      for (int m = 0; m < 2; ++m) {
+        if (l.d_defer[m]) (void)hipFree(l.d_defer[m]);
+        l.d_defer[m] = nullptr;
+      }
+      l.defer_capacity = 0;
+      for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) HIP_TRY(hipMalloc(&l.d_defer[m], (size_t)cap * kDeferRecordBytes));
+      l.defer_capacity = cap;
+    }
   }
   a.defer[0] = reinterpret_cast<uint4 *>(ln.d_defer[0]);
   a.defer[1] = reinterpret_cast<uint4 *>(ln.d_defer[1]);
