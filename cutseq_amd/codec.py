@@ -28,11 +28,17 @@ _lib_tried = False
 _tls = threading.local()
 
 
+_lib_lock = threading.Lock()
+
+
 def libdeflate():
-    """The shared library, or None (then everything goes through zlib)."""
+    """The shared library, or None (then everything goes through zlib).  Loaded and bound once, under a lock."""
     global _lib, _lib_tried
-    if not _lib_tried:
-        _lib_tried = True
+    if _lib_tried:
+        return _lib
+    with _lib_lock:
+        if _lib_tried:
+            return _lib
         for name in ("libdeflate.so.0", "libdeflate.so"):
             try:
                 L = C.CDLL(name)
@@ -50,6 +56,7 @@ def libdeflate():
                                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
             _lib = L
             break
+        _lib_tried = True
     return _lib
 
 
@@ -244,9 +251,12 @@ class GzipSource:
             if pos not in tasks:
                 tasks[pos] = self.pool.submit(self._inflate_member_at, pos, cap[0])
 
+        running = []  # dropped candidates that had started already: they still read the mapped file
+
         def drop(pos):  # a candidate the chain walked past: give its buffer back when (if) it finishes
             fut = tasks.pop(pos, None)
             if fut is not None and not fut.cancel():
+                running.append(fut)
                 fut.add_done_callback(lambda f: f.exception() is None and f.result()[2] is not None and self.give(f.result()[2]))
 
         head = start
@@ -284,6 +294,11 @@ class GzipSource:
         finally:
             for p in list(tasks):
                 drop(p)
+            for fut in running:  # nothing may touch the map once the caller closes the source
+                try:
+                    fut.result()
+                except Exception:  # noqa: BLE001 -- a false candidate; its error is nobody's business
+                    pass
 
     def _members_serial(self, start: int = 0) -> Iterator[tuple]:
         L, d = libdeflate(), _decompressor()

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import mmap
+import os
 import queue
 import threading
 from dataclasses import dataclass
@@ -39,17 +40,27 @@ class _FormatParams(C.Structure):
     ]
 
 
-_bound = False
+_bound = None  # the host library once this module's prototypes are bound (see _lib)
+
+
+_bind_lock = threading.Lock()
 
 
 def _lib():
+    """The host helper library with this module's prototypes bound.  The reader threads of both mates come here
+    at the same moment: the binding happens once, under a lock, on the object that is then published -- a thread
+    must never get a library object whose functions still have default prototypes (a 64-bit buffer address
+    would go through as a C int)."""
     global _bound
-    L = _host_lib()
-    if not _bound:
+    if _bound is not None:
+        return _bound
+    with _bind_lock:
+        if _bound is not None:
+            return _bound
+        L = _host_lib()
         i64, vp = C.c_int64, C.c_void_p
         L.csh_fastq_count.restype = i64
         L.csh_fastq_count.argtypes = [vp, i64, i64, C.c_int, C.POINTER(i64), C.POINTER(C.c_int32)]
-        C.memmove.argtypes = None  # accepts addresses and bytes objects alike
         L.csh_fastq_parse.restype = i64
         L.csh_fastq_parse.argtypes = [vp, i64, i64, C.c_uint32, vp, vp, vp, vp, vp]
         L.csh_format_chunk.restype = i64
@@ -57,7 +68,7 @@ def _lib():
         L.csh_format_chunk_bins.restype = i64
         L.csh_format_chunk_bins.argtypes = ([C.POINTER(_FormatParams), i64, C.c_uint32] + [vp] * 13 +
                                             [vp, C.c_int32, vp, vp, vp] + [vp, vp, vp])
-        _bound = True
+        _bound = L
     return L
 
 

@@ -16,6 +16,7 @@ chunking, threading and rank splits never change the bytes.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 from dataclasses import dataclass
 from pathlib import Path
@@ -45,16 +46,23 @@ class _SynthParams(C.Structure):
 _host = None
 
 
+_host_lock = threading.Lock()
+
+
 def host_lib() -> C.CDLL:
+    """One library object per process (other modules bind their own prototypes on it), created under a lock:
+    threads that start together must not end up with two objects, one of them only half configured."""
     global _host
     if _host is None:
-        if not HOST_LIB_PATH.exists():
-            from . import build
-            build.build_host()
-        L = C.CDLL(str(HOST_LIB_PATH))
-        L.csh_synth_pairs.restype = C.c_int
-        L.csh_synth_pairs.argtypes = [C.POINTER(_SynthParams), C.c_uint32] + [C.c_void_p] * 6 + [C.c_int]
-        _host = L
+        with _host_lock:
+            if _host is None:
+                if not HOST_LIB_PATH.exists():
+                    from . import build
+                    build.build_host()
+                L = C.CDLL(str(HOST_LIB_PATH))
+                L.csh_synth_pairs.restype = C.c_int
+                L.csh_synth_pairs.argtypes = [C.POINTER(_SynthParams), C.c_uint32] + [C.c_void_p] * 6 + [C.c_int]
+                _host = L
     return _host
 
 
