@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import ctypes as C
 import mmap
-import os
 import queue
 import threading
 from dataclasses import dataclass
