@@ -18,7 +18,7 @@ import mmap
 import struct
 import threading
 import zlib
-from typing import Iterator, Optional
+from typing import Iterator
 
 _MEMBER_CAP = 1 << 30   # largest decompressed member taken in one libdeflate call
 _STREAM_BLOCK = 8 << 20
