@@ -583,8 +583,10 @@ def pool_size() -> int:
 def _pool():
     global _POOL
     if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=pool_size())
+        with _bind_lock:  # the reader threads of both mates ask at the same moment: one pool, not two
+            if _POOL is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _POOL = ThreadPoolExecutor(max_workers=pool_size())
     return _POOL
 
 
