@@ -447,3 +447,38 @@ def test_reader_takes_bgzf_and_multi_member_input(tmp_path):
     assert len(want) == 20000
     for name in ("bgzf", "members", "bgzf_then_plain_member"):
         assert records(paths[name]) == want, name
+
+
+def test_library_binding_is_thread_safe():
+    """The reader threads of both mates reach the lazily bound helper libraries at the same moment.  In a fresh
+    interpreter, eight threads released together must all get library objects whose functions carry their
+    prototypes (an unbound csh_fastq_count takes its 64-bit buffer address as a C int: SIGSEGV), and there must
+    be one library object and one worker pool per process."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, threading
+sys.setswitchinterval(1e-6)
+from cutseq_amd import codec, fastq, synth
+start = threading.Barrier(8)
+seen, bad = [], []
+def worker():
+    start.wait()
+    L = fastq._lib()
+    if L.csh_fastq_count.argtypes is None or L.csh_fastq_parse.argtypes is None or L.csh_format_chunk.argtypes is None:
+        bad.append("helper library without prototypes")
+    D = codec.libdeflate()
+    if D is not None and D.libdeflate_gzip_decompress_ex.argtypes is None:
+        bad.append("libdeflate without prototypes")
+    seen.append((id(L), id(synth.host_lib()), id(fastq._pool())))
+threads = [threading.Thread(target=worker) for _ in range(8)]
+[t.start() for t in threads]
+[t.join() for t in threads]
+assert not bad, bad
+assert len(set(seen)) == 1, seen
+print("ok")
+'''
+    root = str(Path(__file__).resolve().parent.parent)
+    for _ in range(4):
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr[-500:])
