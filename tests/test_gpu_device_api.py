@@ -123,3 +123,28 @@ def test_single_end_pipelined_with_second_capture_and_timing_totals():
         (o1, ocap2, _), _m2 = util.oracle_run(tp, b, threads=8)
         assert (out.cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1) == o1).all()
         assert (cap2.cpu().numpy().view(abi.CAP2_DTYPE).reshape(-1) == ocap2).all()
+
+
+def test_four_slots_in_flight_on_three_lanes():
+    """The host-buffer path with more staging slots in flight than the engine has lanes: uploads and scan kernels
+    on the engine stream, resolve kernels and downloads on the resolve stream, a lane reused while its slot's
+    results are still coming back.  Every batch must equal the oracle, in whatever order the slots are synced."""
+    tp = takara_plan()
+    sizes = [9_000, 12_345, 64, 20_000, 1, 15_000, 7_777, 12_000, 3]
+    batches = [synth.generate_pairs(n, 150, first_index=5000 * i + 11) for i, n in enumerate(sizes)]
+    with TrimEngine(tp, device=0, slots=4, max_reads=max(sizes), max_stride=batches[0].stride) as eng:
+        results = [None] * len(batches)
+        in_flight = []
+        for i, b in enumerate(batches):
+            slot = i % 4
+            if len(in_flight) == 4:  # the oldest submission owns this slot
+                j, s = in_flight.pop(0)
+                assert s == slot
+                eng.wait(s)
+            results[i] = eng.submit(slot, b.seq1, b.qual1, b.len1, b.seq2, b.qual2, b.len2)
+            in_flight.append((i, slot))
+        for _, s in reversed(in_flight):  # the rest in reverse order
+            eng.wait(s)
+    for b, (g1, _, g2) in zip(batches, results):
+        o1, o2, _, _ = expect(tp, b)
+        assert (g1 == o1).all() and (g2 == o2).all()
