@@ -18,19 +18,22 @@ collective (weak scaling: every GPU gets its own 4 M-pair batch); torch.distribu
 used for the barrier and the max-over-ranks of the elapsed time.
 
 One JSON line on rank 0, with
-  roofline      algorithmic bytes (616 B/pair = 2 x (150 seq + 150 qual + 8 result)) per
-                launch / average duration of the dominant kernel (the scan kernel; --serial: both kernels)
-                from HIP events on the launch stream, against the 8 TB/s HBM3E peak (``frac_step``: the
-                same bytes over the whole step time); ``traffic`` (HBM bytes per launch) is REPLAYED
-                from the committed counter passes (profiles/r02_pmc_summary.json), not measured in
-                this run;
-  roofline_valu the bound that actually governs: VALU wave-instructions per launch (same replayed
-                counter file, both kernels) x the measured issue cost per instruction / (1024 SIMDs x
-                clock x step time of THIS run);
-  cpu_baseline  the CPU oracle (own scalar C restatement of the cutseq->cutadapt chain --
-                cutadapt itself is not installable here) timed on this box's host cores on a
-                bounded sample of the same batch; the GPU results for that sample are
-                compared bit-for-bit while at it.
+  roofline      algorithmic bytes (616 B/pair = 2 x (150 seq + 150 qual + 8 result)) per launch over the launch
+                duration, against the 8 TB/s HBM3E peak.  Pipelined form: the duration is the step time (the scan
+                kernel plus what the overlapped resolve kernel adds), ``frac_scan_kernel`` / ``kernel_ms_avg`` keep
+                the scan kernel alone (HIP events on the launch stream, cs_kernel_time_totals); --serial: both
+                kernels, event-timed.  ``traffic`` (HBM bytes per launch) is REPLAYED from the newest committed
+                counter passes (profiles/rNN_pmc_summary.json) and only when that file carries the sha256 of the
+                kernel sources this run uses -- otherwise it is null and ``traffic_source`` says why;
+  roofline_valu the bound that actually governs: VALU wave-instructions per launch (same replayed counter file, both
+                kernels) x 2 cycles (spec issue cost of a wave64 instruction on a SIMD-32) / (1024 SIMDs x the clock
+                measured in the counter passes x step time of THIS run), plus the same at this kernel's measured mix
+                ceiling (2.3 cycles) and the scan kernel's SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES;
+  cpu_baseline  the CPU oracle (own scalar C restatement of the cutseq->cutadapt chain -- cutadapt itself is not
+                installable here; when it is, ``cpu_baseline_cutadapt`` times the real chain beside it) on this box's
+                host cores on a bounded sample of the same batch; the GPU results for that sample are compared
+                bit-for-bit while at it (``all_ranks_identical``).  With N > 1 every rank checks a 200 k-pair sample
+                of its own shard against the oracle and rank 0 reports the MIN over ranks.
 """
 from __future__ import annotations
 
@@ -48,46 +51,19 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from cutseq_amd import abi, plan as planmod, shard, synth  # noqa: E402
-from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig  # noqa: E402
+from cutseq_amd import abi, shard, workloads  # noqa: E402
+from cutseq_amd.build import kernel_source_hash  # noqa: E402
 from cutseq_amd.engine import TrimEngine  # noqa: E402
+from cutseq_amd.workloads import CONFIG4_SCHEME, READ_LEN  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-READ_LEN = 150
-N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
-# issue cost of one VALU wave-instruction on a SIMD, measured on this part for this kernel's mix of full-
-# and half-rate opcodes (tools/micro/valu_ops.hip): ~85 % at 2.3 cycles, the rest at 4.5
-VALU_CYCLES_PER_INSTR = 2.65
-# BASELINE config 4: inline barcode + 8-nt UMI + dual adapters, --ensure-inline-barcode
-CONFIG4_SCHEME = "ACACGACGCTCTTCCGATCT(ATCACG)NNNNNNNN>AGATCGGAAGAGCACACGTC"
-# BASELINE config 5 (extension, not a reference capability): 96-plex inline-barcode demultiplex + dual adapters + q-trim
-CONFIG5_PLEX, CONFIG5_LEN = 96, 8
-
-
-def config5_barcodes(seed: int = 96):
-    """96 barcodes of 8 nt, pairwise edit distance >= 3 (seeded greedy pick)."""
-    import random
-    rng = random.Random(seed)
-
-    def dist(a, b):
-        prev = list(range(len(b) + 1))
-        for i, ca in enumerate(a, 1):
-            cur = [i]
-            for j, cb in enumerate(b, 1):
-                cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
-            prev = cur
-        return prev[-1]
-
-    codes = []
-    while len(codes) < CONFIG5_PLEX:
-        c = "".join(rng.choice("ACGT") for _ in range(CONFIG5_LEN))
-        if all(dist(c, o) >= 3 for o in codes):
-            codes.append(c)
-    return codes
-
-
-def config5_scheme(codes):
-    return f"ACACGACGCTCTTCCGATCT({codes[0]})>AGATCGGAAGAGCACACGTC"
+N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
+# A wave64 VALU instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md, "Wave scheduling"): the spec
+# ceiling.  tools/micro/valu_ops.hip reaches it for and/or/xor/add/sub/bitop3 once the MEASURED clock is used
+# (0.42 instr/clk at the nominal 2.4 GHz = 0.50 at the ~2.0 GHz the part holds under this load); the half-rate
+# opcodes of this kernel's mix (shifts left, v_perm, compares: ~15 %) make its own ceiling 2.3 cycles.
+VALU_CYCLES_SPEC, VALU_CYCLES_MIX = 2.0, 2.3
+PARITY_SAMPLE = 200_000  # pairs every rank checks against the oracle when world > 1
 
 
 def parse_args():
@@ -101,29 +77,31 @@ def parse_args():
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
     ap.add_argument("--serial", action="store_true", help="both kernels of a step on one stream (no overlap between steps)")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the HBM copy-bandwidth probe")
-    ap.add_argument("--traffic-json", type=str, default=str(ROOT / "profiles" / "r02_pmc_summary.json"),
+    ap.add_argument("--traffic-json", type=str, default=str(default_traffic_json()),
                     help="JSON with HBM bytes per launch measured in separate rocprofv3 --pmc passes (tools/pmc.sh)")
     return ap.parse_args()
 
 
-def make_plan(workload: str, use_filter: bool):
-    if workload == "config2":
-        tp = planmod.single_adapter_plan("AGATCGGAAGAGC", 0.1, 3, min_length=0)
-    elif workload == "config4":
-        st = planmod.CutadaptConfig()
-        st.ensure_inline_barcode = True
-        tp = planmod.compile_paired(BarcodeConfig(CONFIG4_SCHEME), st)
-    elif workload == "config5":
-        codes = config5_barcodes()
-        st = planmod.CutadaptConfig()
-        st.demux_barcodes = codes
-        tp = planmod.compile_paired(BarcodeConfig(config5_scheme(codes)), st)
-    else:
-        st = planmod.CutadaptConfig()
-        st.trim_polyA = True
-        tp = planmod.compile_paired(BarcodeConfig(BUILDIN_ADAPTERS["TAKARAV3"]), st)
-    tp.use_filter = use_filter
-    return tp
+def default_traffic_json() -> Path:
+    """The newest committed counter summary (profiles/rNN_pmc_summary.json)."""
+    found = sorted((ROOT / "profiles").glob("r[0-9][0-9]_pmc_summary.json"))
+    return found[-1] if found else ROOT / "profiles" / "r02_pmc_summary.json"
+
+
+def replayed_counters(path: str, n: int):
+    """Counters of the committed rocprofv3 --pmc passes, replayed only when they were collected on THESE kernel
+    sources (sha256 written by tools/summarize_pmc.py) and on this launch shape -> (dict | None, why not)."""
+    p = Path(path)
+    if not p.exists():
+        return None, f"{p.name} not found"
+    pm = json.loads(p.read_text())
+    if pm.get("pairs_per_launch") != n:
+        return None, f"{p.name} was collected on {pm.get('pairs_per_launch')} pairs per launch, this run uses {n}"
+    have, want = pm.get("kernel_source_sha256"), kernel_source_hash()
+    if have != want:
+        return None, (f"{p.name} was collected on other kernel sources (sha256 {str(have)[:12]}.. != {want[:12]}..): "
+                      "re-run tools/pmc.sh + tools/summarize_pmc.py")
+    return pm, None
 
 
 def main():
@@ -151,31 +129,13 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    paired = args.workload != "config2"
-    tp = make_plan(args.workload, not args.no_filter)
+    paired = workloads.is_paired(args.workload)
+    tp = workloads.make_plan(args.workload, not args.no_filter)
     n = args.pairs
     # every rank trims its own shard of the read stream (weak scaling: world * n reads in all), no exchange step
     first, last = shard.shard_bounds(world * n, rank, world)
     assert last - first == n
-    if args.workload == "config5":
-        codes = config5_barcodes()
-        batch = synth.generate_pairs(n, READ_LEN, config5_scheme(codes), first_index=first)
-        # every pair gets one of the 96 barcodes (2 % get none of them), 1 % sequencing error per base on top
-        rng = np.random.default_rng(first + 5)
-        table = np.frombuffer("".join(codes).encode(), dtype=np.uint8).reshape(CONFIG5_PLEX, CONFIG5_LEN)
-        pick = rng.integers(0, CONFIG5_PLEX, size=n)
-        bc_bases = table[pick].copy()
-        foreign = rng.random(n) < 0.02
-        bc_bases[foreign] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(int(foreign.sum()), CONFIG5_LEN))]
-        err = rng.random((n, CONFIG5_LEN)) < 0.01
-        bc_bases[err] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(err.sum()))]
-        batch.seq1[:, :CONFIG5_LEN] = bc_bases
-    elif args.workload == "config4":
-        batch = synth.generate_pairs(n, READ_LEN, CONFIG4_SCHEME, first_index=first)
-    elif paired:
-        batch = synth.generate_pairs(n, READ_LEN, first_index=first)
-    else:
-        batch = synth.generate_single_adapter(n, READ_LEN, first_index=first)
+    batch = workloads.make_batch(args.workload, n, first_index=first)  # the generator the parity tests use
     stride = batch.stride
 
     def up(a):
@@ -244,15 +204,19 @@ def main():
     bytes_per_unit = (2 if paired else 1) * (2 * READ_LEN + 8) + (1 if args.workload == "config5" else 0)  # + barcode byte
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     step_s = elapsed / args.steps
-    achieved = bytes_per_unit * units_per_step / avg_kernel_s / 1e9
-    traffic = valu_insts = None
-    traffic_source = None
-    if args.workload == "config3" and args.traffic_json and Path(args.traffic_json).exists():
-        pm = json.loads(Path(args.traffic_json).read_text())
-        if pm.get("pairs_per_launch") == n:  # counters were collected on this very launch shape
-            traffic = pm.get("hbm_bytes_per_launch")
-            valu_insts = pm.get("valu_insts_per_launch")
-            traffic_source = f"replayed from {Path(args.traffic_json).name} (separate rocprofv3 --pmc passes, tools/pmc.sh)"
+    # Pipelined form: a step's bytes (both mates, every result) are spread over the scan kernel AND the resolve
+    # kernel that hides under the next step's scan kernel, so the step time is the honest denominator; the
+    # scan-kernel-only figure stays as a secondary field.  Serial form: both kernels, event-timed.
+    launch_s = avg_kernel_s if args.serial else max(step_s, avg_kernel_s)
+    achieved = bytes_per_unit * units_per_step / launch_s / 1e9
+    achieved_scan = bytes_per_unit * units_per_step / avg_kernel_s / 1e9
+    counters, why_not = (None, "counters are kept for the headline workload (config3) only")
+    if args.workload == "config3" and args.traffic_json:
+        counters, why_not = replayed_counters(args.traffic_json, n)
+    traffic = counters.get("hbm_bytes_per_launch") if counters else None
+    valu_insts = counters.get("valu_insts_per_launch") if counters else None
+    traffic_source = (f"replayed from {Path(args.traffic_json).name} (separate rocprofv3 --pmc passes on these kernel "
+                      f"sources, tools/pmc.sh)") if counters else f"null: {why_not}"
 
     st1, st2 = eng.stats()
     result = {
@@ -280,8 +244,7 @@ def main():
             }[args.workload],
             "pairs_per_step_per_gpu": n,
             "read_len": READ_LEN,
-            "scheme": {"config3": "TAKARAV3", "config2": "-a AGATCGGAAGAGC", "config4": CONFIG4_SCHEME,
-                       "config5": "P5(96 x 8 nt)>P7 --demux-barcodes"}[args.workload],
+            "scheme": workloads.scheme_label(args.workload),
             "prefilter": not args.no_filter,
             "pipeline": "serial" if args.serial else "resolve kernel of step i under the scan kernel of step i+1 (2 streams, 3 result sets)",
             "parallelism": f"shard{world}" if world > 1 else "single",
@@ -294,7 +257,12 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBPS, 5),
             "traffic": traffic,
             "traffic_source": traffic_source,
-            "frac_step": round(bytes_per_unit * units_per_step / step_s / 1e9 / HBM_PEAK_GBPS, 5),
+            "launch_ms": round(launch_s * 1e3, 4),
+            "launch_ms_note": ("scan + resolve kernel, HIP events on the launch stream" if args.serial else
+                               "whole step (scan kernel + what the overlapped resolve kernel adds); the scan kernel alone "
+                               "is achieved_scan_kernel / frac_scan_kernel / kernel_ms_avg"),
+            "achieved_scan_kernel": round(achieved_scan, 2),
+            "frac_scan_kernel": round(achieved_scan / HBM_PEAK_GBPS, 5),
             "kernel": ("csdev::trim_kernel<.., MODE_SCAN> + <.., MODE_RESOLVE> (one launch of each per step, one stream)"
                        if args.serial else
                        "csdev::trim_kernel<.., MODE_SCAN> (dominant; the step's <.., MODE_RESOLVE> launch runs on the "
@@ -306,13 +274,25 @@ def main():
         "exact_dp_fraction": round((st1.n_exact_dp + st2.n_exact_dp) / max(1, st1.n_reads + st2.n_reads), 4),
     }
     if valu_insts:
-        # the bound that governs: VALU issue slots.  achieved / peak in wave-instructions per second.
-        peak = N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_INSTR
+        # The bound that governs: VALU issue slots, priced with the clock MEASURED in the same counter passes
+        # (GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 / kernel duration, MI355X_MICROARCH.md "DVFS give-back").
+        scan = counters.get("per_kernel", {}).get("scan", {})
+        clock_hz = counters.get("measured_clock_hz") or MAX_CLOCK_HZ
         ach = valu_insts / (avg_kernel_s if args.serial else step_s)  # both kernels' instructions per step
+        peak_spec = N_SIMD * clock_hz / VALU_CYCLES_SPEC
+        wave_cycles = scan.get("SQ_WAVE_CYCLES", {}).get("mean_per_launch")
+        wait_inst = scan.get("SQ_WAIT_INST_ANY", {}).get("mean_per_launch")
+        wait_any = scan.get("SQ_WAIT_ANY", {}).get("mean_per_launch")
         result["roofline_valu"] = {
-            "bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
-            "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
-            "valu_insts_per_launch": valu_insts, "cycles_per_instr": VALU_CYCLES_PER_INSTR,
+            "bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(peak_spec / 1e9, 2),
+            "unit": "G wave-instr/s", "frac": round(ach / peak_spec, 4),
+            "cycles_per_instr": VALU_CYCLES_SPEC,
+            "clock_hz": round(clock_hz), "clock_source": counters.get("measured_clock_source", "nominal 2.4 GHz (no GRBM_GUI_ACTIVE pass)"),
+            "frac_at_mix_ceiling": round(ach / (N_SIMD * clock_hz / VALU_CYCLES_MIX), 4),
+            "mix_ceiling_cycles_per_instr": VALU_CYCLES_MIX,
+            "valu_insts_per_launch": valu_insts,
+            "scan_wait_inst_any_over_wave_cycles": round(wait_inst / wave_cycles, 4) if wait_inst and wave_cycles else None,
+            "scan_wait_any_over_wave_cycles": round(wait_any / wave_cycles, 4) if wait_any and wave_cycles else None,
             "source": traffic_source,
         }
 
@@ -338,7 +318,7 @@ def main():
         del src, dst
 
     if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "config5":
-        # (config 5 has no single CPU counterpart: its parity definition is 96 oracle runs, tests/test_gpu_demux.py)
+        # (config 5 has no single CPU counterpart: its parity definition is 96 oracle runs, tests/test_gpu_workloads.py)
         import oracle  # the checker, timed as the CPU baseline; never part of the product path
         m = min(args.cpu_sample, n)
         threads = oracle.host_threads()
@@ -365,14 +345,43 @@ def main():
                       "cutadapt is not installable here",
             "gpu_results_identical_on_sample": same,
         }
+        result["all_ranks_identical"] = same
         if not same:
             result["parity_error"] = "GPU results differ from the oracle on the CPU sample"
+        # when an image ships cutadapt, time the real cutseq -> cutadapt chain beside it (never here so far)
+        try:
+            from tools import pin_against_cutadapt as pin
+            extra = pin.time_cutadapt_chain(args.workload, batch, min(m, 200_000)) if pin.cutadapt_available() else None
+        except Exception as exc:  # the probe must never take the bench line down
+            extra = {"error": f"{type(exc).__name__}: {exc}"}
+        if extra:
+            result["cpu_baseline_cutadapt"] = extra
+    if world > 1 and args.workload != "config5":
+        # An N-GPU rate without a parity gate is not a result: every rank checks a sample of ITS OWN shard against
+        # the oracle (the host cores are shared by the ranks), rank 0 reports whether all of them agreed.
+        import oracle
+        m = min(PARITY_SAMPLE, n)
+        threads = max(1, oracle.host_threads() // world)
+        a1, n1, a2, n2 = tp.pack()
+        params = tp.params()
+        o1, _, _ = oracle.trim_mate(a1, n1, params, batch.seq1[:m], batch.qual1[:m], batch.len1[:m], threads=threads)
+        same = bool(np.array_equal(out1[:m].cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1), o1))
+        if paired:
+            o2, _, _ = oracle.trim_mate(a2, n2, params, batch.seq2[:m], batch.qual2[:m], batch.len2[:m], threads=threads)
+            same = same and bool(np.array_equal(out2[:m].cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1), o2))
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        result["all_ranks_identical"] = bool(int(flag.item()))
+        result["parity_check"] = (f"every rank: first {m} {'pairs' if paired else 'reads'} of its own shard against the "
+                                  f"CPU oracle, {threads} threads per rank; MIN over ranks")
+        if not result["all_ranks_identical"]:
+            result["parity_error"] = "GPU results differ from the oracle on some rank's sample"
     if rank == 0:
         print(json.dumps(result))
     eng.close()
     if world > 1:
         dist.destroy_process_group()
-    if rank == 0 and result.get("parity_error"):
+    if result.get("parity_error"):  # (every rank holds the reduced verdict)
         sys.exit(3)
 
 

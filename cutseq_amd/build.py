@@ -13,6 +13,16 @@ DEPS = [SRC, HERE / "csrc" / "trim_kernel.hip.inc", HERE.parent / "include" / "c
 OUT = HERE / "libcutseq_hip.so"
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the device sources: counter files under profiles/ carry it, bench.py replays a file only when
+    it was collected on the kernels it is running (tools/summarize_pmc.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in (HERE / "csrc" / "trim_kernel.hip.inc", SRC):
+        h.update(path.read_bytes())
+    return h.hexdigest()
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(exe).exists():

@@ -20,7 +20,10 @@ import threading
 import zlib
 from typing import Iterator
 
-_MEMBER_CAP = 1 << 30   # largest decompressed member taken in one libdeflate call
+# Largest decompressed member taken in one libdeflate call.  A member that does not fit the first buffer is tried
+# ONCE more at this size and then streamed through zlib: a multi-gigabyte single-member file (the usual sequencer
+# output) is not inflated from its start over and over, and no gigabyte buffers pile up in the arena.
+_MEMBER_CAP = 256 << 20
 _STREAM_BLOCK = 8 << 20
 
 _lib = None
@@ -220,7 +223,7 @@ class GzipSource:
                                                  C.byref(n_out))
             if rc == 3 and out.size < _MEMBER_CAP:
                 self.give(out)
-                out = self.take(min(_MEMBER_CAP, 4 * out.size))
+                out = self.take(_MEMBER_CAP)
                 continue
             break
         if rc != 0:
@@ -316,7 +319,7 @@ class GzipSource:
                                                      C.byref(n_out))
                 if rc == 3 and out.size < _MEMBER_CAP:
                     self.give(out)
-                    cap = min(_MEMBER_CAP, 4 * cap)
+                    cap = _MEMBER_CAP
                     out = self.take(cap)
                     continue
                 break

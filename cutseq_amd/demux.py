@@ -10,6 +10,8 @@ outcomes: "equal to B independent ``--ensure-inline-barcode`` runs" holds by con
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from . import abi
@@ -72,11 +74,15 @@ def build_table(op: DemuxOp, device: int = 0, select_rule: int = abi.CS_SELECT_L
     return np.ascontiguousarray(table, dtype=np.uint16)
 
 
+_table_lock = threading.Lock()
+
+
 def ensure_tables(plan: TrimPlan, device: int = 0) -> None:
-    """Build the tables the plan's demultiplexing ops still lack."""
-    for _mate, _i, op in plan.demux_ops():
-        if op.table is None:
-            op.table = build_table(op, device, plan.select_rule, plan.indel_tie)
+    """Build the tables the plan's demultiplexing ops still lack (once: engines of several devices share the plan)."""
+    with _table_lock:
+        for _mate, _i, op in plan.demux_ops():
+            if op.table is None:
+                op.table = build_table(op, device, plan.select_rule, plan.indel_tie)
 
 
 def ambiguous_prefixes(op: DemuxOp) -> int:
@@ -108,4 +114,7 @@ def read_barcode_file(path: str):
                 codes.append(fields[1].upper())
     if len(set(names)) != len(names):
         raise ValueError(f"{path}: duplicate barcode name")
+    for name in names:  # names become parts of output file names
+        if not name or name in (".", "..") or any(c in name for c in "/\\\0") or name != name.strip():
+            raise ValueError(f"{path}: barcode name {name!r} cannot be used in a file name")
     return names, codes

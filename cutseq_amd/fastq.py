@@ -13,6 +13,7 @@ import ctypes as C
 import mmap
 import queue
 import threading
+import time
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Optional, Sequence
@@ -116,7 +117,11 @@ class _Arena:
             self._all_pinned.append((ptr, arr))
         return arr
 
+    _KEEP_MAX = 96 << 20  # larger buffers (one huge gzip member) are unmapped instead of kept for the whole run
+
     def give(self, arr: np.ndarray) -> None:
+        if arr.size > self._KEEP_MAX and not self._pinned:
+            return
         with self._lock:
             stack = self._free.setdefault(arr.size, [])
             if len(stack) < self._keep:
@@ -265,13 +270,16 @@ class _Reader:
         return False
 
     def _inflate(self):
+        gen = self.src.blocks()
         try:
-            for block in self.src.blocks():
+            for block in gen:
                 if self._stop or not self._put(self._blocks, block):
                     return
             self._put(self._blocks, None)
         except BaseException as exc:
             self._put(self._blocks, _Failure(exc))
+        finally:
+            gen.close()  # the generator's own clean-up waits for every pool task that still reads the mapped file
 
     def _fill(self, buf: np.ndarray, fill: int):
         """More text behind buf[:fill] -> (buf, fill, eof); the buffer grows when it has to."""
@@ -346,13 +354,22 @@ class _Reader:
         return item.result() if item is not None else None
 
     def close(self):
+        """Stop the reader.  The source (an mmap for gzip input) is closed only after the reader threads -- and with
+        them every inflate task of the pool that holds a raw address into the map -- are done: closing it under
+        them would unmap memory a libdeflate call is still reading."""
         self._stop = True
-        for q in (self._blocks, self.halves):  # unblock producers
-            try:
-                while True:
-                    q.get_nowait()
-            except queue.Empty:
-                pass
+        deadline = time.monotonic() + 30.0
+        while any(t.is_alive() for t in self._threads) and time.monotonic() < deadline:
+            for q in (self._blocks, self.halves):  # unblock producers
+                try:
+                    while True:
+                        q.get_nowait()
+                except queue.Empty:
+                    pass
+            for t in self._threads:
+                t.join(timeout=0.05)
+        if any(t.is_alive() for t in self._threads):
+            return  # a thread is stuck in I/O: leak the mapping rather than pull it away under the thread
         self.src.close()
 
 
@@ -573,11 +590,24 @@ def finish_chunk(chunk: Chunk, plan, res1, cap2, res2, gz: Sequence[Sequence[Opt
 
 
 _POOL = None
+_THREADS = None  # -t/--threads of the CLI: upper bound of the host pool (None = every usable core)
+
+
+def set_threads(n) -> None:
+    """Bound the host thread pool (parse / format / inflate / deflate jobs) -- what ``-t`` means here: the reference
+    hands it to ``make_runner(inpaths, cores=N)`` (cutseq/run.py:436, 753, 998-1003), where it is the number of
+    worker processes; the per-read work of this engine runs on the GPU, the host threads feed it.  Must be called
+    before the first chunk is read (the pool is created once)."""
+    global _THREADS
+    if _POOL is not None and n != _THREADS:
+        raise RuntimeError("the host pool is already running")
+    _THREADS = None if n is None else max(1, int(n))
 
 
 def pool_size() -> int:
     from .synth import usable_cpus
-    return max(2, usable_cpus(32))
+    cores = max(2, usable_cpus(32))
+    return cores if _THREADS is None else min(cores, _THREADS)
 
 
 def _pool():

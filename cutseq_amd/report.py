@@ -109,9 +109,13 @@ def minimal_report(tp: TrimPlan, totals: dict) -> str:
 
 
 def error_lengths(op: AdapterOp) -> list:
-    """cutadapt ``ErrorRanges.lengths()``: for 1, 2, ... allowed errors the longest match that still allows one
-    error fewer -- a function of adapter length and error rate only (rate 0.2, 20 nt: [4, 9, 14, 19])."""
-    return [int(errors / op.max_error_rate) - 1 for errors in range(1, int(op.max_error_rate * op.m) + 1)]
+    """cutadapt ``ErrorRanges._compute_lengths``: for 1, 2, ... allowed errors the longest match that still allows
+    one error fewer, and "the last number is always the adapter length" (appended when the list is empty or ends
+    below it) -- rate 0.2, 20 nt: [4, 9, 14, 19, 20]; an adapter that allows no error at all: [m]."""
+    lengths = [int(errors / op.max_error_rate) - 1 for errors in range(1, int(op.max_error_rate * op.m) + 1)]
+    if not lengths or lengths[-1] < op.m:
+        lengths.append(op.m)
+    return lengths
 
 
 def _adapter_json(op: AdapterOp, name: str, matches: int) -> dict:

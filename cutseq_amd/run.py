@@ -6,8 +6,8 @@ preset resolution and upper-casing (1041-1056), same output naming (1058-1107), 
 paired dispatch (842-863).  Where the reference assembles cutadapt modifiers and calls
 ``runner.run``, this compiles the op table (``plan.compile_*``) and streams record-aligned FASTQ
 chunks through :class:`cutseq_amd.engine.TrimEngine` (one per visible GPU, chunks round-robin,
-ordered write-back).  ``-t/--threads`` is accepted for compatibility; the per-read work runs on
-the GPU(s).
+ordered write-back).  ``-t/--threads`` bounds the host thread pool that parses, formats and (de)compresses
+(the reference passes it to ``make_runner(cores=N)``, run.py:436, 753); the per-read work runs on the GPU(s).
 """
 from __future__ import annotations
 
@@ -71,7 +71,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--auto-rc", action="store_true",
                    help="Automatically reverse complement reads if the library strand is '-'. "
                         "For paired-end, R1 and R2 will be swapped.")
-    p.add_argument("-t", "--threads", type=int, default=1, help="Accepted for compatibility. (Default: 1)")
+    p.add_argument("-t", "--threads", type=int, default=None,
+                   help="Number of host threads for FASTQ parsing, formatting and (de)compression "
+                        "(Default: all usable cores; the per-read work runs on the GPU).")
     p.add_argument("-n", "--dry-run", action="store_true",
                    help="Print the sequence of modifier steps instead of running the pipeline.")
     p.add_argument("-V", "--version", action="version", version=f"%(prog)s {__version__}")
@@ -169,7 +171,7 @@ def settings_from_args(args) -> CutadaptConfig:
     st.trim_polyA = args.trim_polyA
     st.trim_polyA_wo_direction = args.trim_polyA_wo_direction
     st.conditional_cutter = args.conditional_cutter
-    st.threads = args.threads
+    st.threads = args.threads if args.threads is not None else 0
     st.min_length = args.min_length
     st.min_quality = args.min_quality
     st.dry_run = args.dry_run
@@ -304,6 +306,13 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     n_dev = capi.device_count()
     if n_dev <= 0:
         raise capi.HipUnavailable("no HIP device visible; cutseq_amd has no CPU trimming path")
+    if getattr(args, "threads", None) is not None:
+        if args.threads < 1:
+            _fail("-t/--threads must be at least 1.")
+        try:
+            fastq.set_threads(args.threads)
+        except RuntimeError:  # a second run in one process (tests): the pool of the first run stays
+            logging.warning("-t/--threads ignored: the host thread pool of this process is already running.")
     want = os.environ.get("CUTSEQ_DEVICES")  # e.g. "0,1,2,3"; a device may be listed twice (two engines on it)
     devices = [int(x) for x in want.split(",")] if want else list(range(n_dev))
     chunk_reads = int(os.environ.get("CUTSEQ_CHUNK_READS", fastq.CHUNK_READS))
@@ -332,6 +341,9 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     pool = fastq._pool()
     max_finishing = fastq.pool_size() + 2  # chunks being formatted / compressed (about 90 MB each)
     done: "queue.Queue" = queue.Queue()
+    if tp.demux is not None:
+        from . import demux  # look-up tables once, here: every device worker would otherwise build its own
+        demux.ensure_tables(tp, devices[0])
     workers = [_DeviceWorker(tp, dev, done, chunk_reads) for dev in devices]
     failure: List[BaseException] = []
 
@@ -440,7 +452,10 @@ class ReadTooLong(ValueError):
 def run_cutseq(args):
     barcode = BarcodeConfig(args.adapter_scheme)
     settings = settings_from_args(args)
-    tp = compile_plan(args, barcode, settings)
+    try:
+        tp = compile_plan(args, barcode, settings)
+    except ValueError as exc:  # e.g. a barcode list the demultiplexer cannot take: the CLI's exit style, no traceback
+        _fail(str(exc))
     if settings.dry_run:
         dry_run(tp, barcode)
         return None

@@ -239,7 +239,7 @@ def test_reports_from_oracle_results():
     assert a["five_prime_end"]["sequence"] == op1.sequence and a["three_prime_end"] is None
     assert a["five_prime_end"]["trimmed_lengths"] == []
     # cutadapt's ErrorRanges for a 20-nt adapter at rate 0.2: one error from 5 nt, two from 10, ... (guide: "error tolerance")
-    assert a["five_prime_end"]["error_lengths"] == [4, 9, 14, 19]
+    assert a["five_prime_end"]["error_lengths"] == [4, 9, 14, 19, 20]  # "the last number is always the adapter length"
     assert rep["schema_version"] == [0, 3] and rep["cutadapt_version"].startswith("5.0+")
 
     def no_none_under(node, path=""):
@@ -482,3 +482,75 @@ print("ok")
     for _ in range(4):
         out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr[-500:])
+
+
+def test_threads_flag_bounds_the_host_pool(monkeypatch):
+    """-t/--threads (reference: make_runner(cores=N), cutseq/run.py:436, 753, 998-1003) caps the host thread pool;
+    without it every usable core is used."""
+    monkeypatch.setattr(fastq, "_POOL", None)
+    monkeypatch.setattr(fastq, "_THREADS", None)
+    everything = fastq.pool_size()
+    assert everything >= 2
+    fastq.set_threads(1)
+    assert fastq.pool_size() == 1
+    fastq.set_threads(3)
+    assert fastq.pool_size() == min(3, everything)
+    pool = fastq._pool()
+    assert pool._max_workers == min(3, everything)
+    with pytest.raises(RuntimeError):
+        fastq.set_threads(5)  # the pool is running: its size is fixed
+    pool.shutdown()
+    args = cli.build_parser().parse_args(["-A", "TAKARAV3", "-t", "4", "x_R1.fq.gz"])
+    assert args.threads == 4 and cli.build_parser().parse_args(["-A", "TAKARAV3", "x.fq"]).threads is None
+
+
+def test_one_huge_gzip_member_is_streamed_not_reinflated(tmp_path, monkeypatch):
+    """A member beyond the one-call cap is tried once at the cap and then streamed through zlib: same
+    bytes, and the arena keeps no giant buffers."""
+    from cutseq_amd import codec
+    body = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(60_000))
+    path = tmp_path / "big.fq.gz"
+    path.write_bytes(gzip.compress(body, 1))
+    monkeypatch.setattr(codec, "_MEMBER_CAP", 1 << 20)  # the ~1.7 MB member no longer fits one call
+    takes = []
+
+    def take(n):
+        takes.append(n)
+        return np.empty(n, dtype=np.uint8)
+
+    src = codec.GzipSource(str(path), fastq._pool(), take, lambda a: None)
+    got = b"".join(bytes(memoryview(b)[:n]) for b, n in src.blocks())
+    src.close()
+    assert got == body
+    assert max(takes) <= 32 << 20 and sum(1 for t in takes if t >= (1 << 20)) <= 4  # no escalation ladder
+    big = np.empty(fastq._Arena._KEEP_MAX + 1, dtype=np.uint8)
+    fastq.ARENA.give(big)
+    assert big.size not in fastq.ARENA._free or not any(a is big for a in fastq.ARENA._free[big.size])
+
+
+def test_barcode_names_must_be_usable_in_file_names(tmp_path):
+    from cutseq_amd import demux
+    good = tmp_path / "ok.tsv"
+    good.write_text("a1\tACGTAC\nb2\tTTGACC\n")
+    assert demux.read_barcode_file(str(good)) == (["a1", "b2"], ["ACGTAC", "TTGACC"])
+    for bad in ("../x\tACGTAC\n", "a/b\tACGTAC\n", "..\tACGTAC\n"):
+        p = tmp_path / "bad.tsv"
+        p.write_text(bad)
+        with pytest.raises(ValueError):
+            demux.read_barcode_file(str(p))
+
+
+def test_replayed_counters_need_matching_kernel_sources(tmp_path):
+    """bench.py replays profiles/*_pmc_summary.json only when it was collected on the kernels it runs."""
+    import bench
+    from cutseq_amd.build import kernel_source_hash
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps({"pairs_per_launch": 1000, "kernel_source_sha256": "0" * 64, "hbm_bytes_per_launch": 1}))
+    got, why = bench.replayed_counters(str(f), 1000)
+    assert got is None and "other kernel sources" in why
+    f.write_text(json.dumps({"pairs_per_launch": 1000, "kernel_source_sha256": kernel_source_hash(), "hbm_bytes_per_launch": 7}))
+    got, why = bench.replayed_counters(str(f), 1000)
+    assert why is None and got["hbm_bytes_per_launch"] == 7
+    got, why = bench.replayed_counters(str(f), 2000)
+    assert got is None and "pairs per launch" in why
+    assert bench.replayed_counters(str(tmp_path / "nope.json"), 1)[0] is None

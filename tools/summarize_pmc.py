@@ -8,6 +8,10 @@ import glob
 import json
 import os
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from cutseq_amd.build import kernel_source_hash  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
@@ -25,17 +29,33 @@ for pass_dir in sorted(glob.glob("gpurun_out/pmc/*/")):
     if not fs:
         continue
     agg = collections.defaultdict(list)
+    dur = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[-1])):
         k = kernel_of(r["Kernel_Name"])
         if k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if r.get("End_Timestamp") and r.get("Start_Timestamp"):
+                dur[(k, r["Counter_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for (k, c), v in agg.items():
         per[k][c] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+        if dur.get((k, c)):
+            per[k][c]["mean_duration_ns"] = sum(dur[(k, c)]) / len(dur[(k, c)])
 total = {}
 for c in set(per["scan"]) | set(per["resolve"]):
     total[c] = sum(per[k][c]["mean_per_launch"] for k in per if c in per[k])
 fetch, write = total["FETCH_SIZE"], total["WRITE_SIZE"]
+# the clock the part held while the scan kernel ran: GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md,
+# "DVFS give-back"), the duration is the same dispatches' own, from the same pass
+clock_hz, clock_src = None, None
+grbm = per["scan"].get("GRBM_GUI_ACTIVE")
+if grbm and grbm.get("mean_duration_ns"):
+    clock_hz = grbm["mean_per_launch"] / 8.0 / (grbm["mean_duration_ns"] * 1e-9)
+    clock_src = ("GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration of the scan kernel, same rocprofv3 pass "
+                 f"({grbm['mean_per_launch']:.4g} / 8 / {grbm['mean_duration_ns'] / 1e6:.4f} ms)")
 summary = {
+    "kernel_source_sha256": kernel_source_hash(),
+    "measured_clock_hz": clock_hz,
+    "measured_clock_source": clock_src,
     "command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 "
                "--no-copy-probe (one pass per counter set of at most three SQ counters: tools/pmc.sh)",
     "kernels": {"scan": "csdev::trim_kernel<true,false,0>", "resolve": "csdev::trim_kernel<true,false,1>"},
