@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-CS_ABI_VERSION = 3
+CS_ABI_VERSION = 4
 CS_MAX_ADAPTER = 128
 CS_MAX_OPS = 24
 CS_MAX_STRIDE = 1536
@@ -127,6 +127,35 @@ class cs_reads(C.Structure):
     ]
 
 
+CS_TEXT_OK, CS_TEXT_ERR_MALFORMED, CS_TEXT_ERR_TOO_LONG, CS_TEXT_ERR_IDS_DIFFER, CS_TEXT_ERR_LINE_COUNT = 0, 1, 2, 3, 4
+
+
+class cs_text_params(C.Structure):
+    _fields_ = [
+        ("has_umi", C.c_uint8),
+        ("untrimmed_filter", C.c_uint8),
+        ("reverse_complement", C.c_uint8),
+        ("_pad", C.c_uint8),
+        ("max_tag", C.c_uint32),
+        ("suffix1", C.c_char_p * 2),
+        ("suffix2", C.c_char_p * 2),
+    ]
+
+
+class cs_text_result(C.Structure):
+    _fields_ = [
+        ("error", C.c_int32),
+        ("error_record", C.c_uint32),
+        ("max_len", C.c_uint32),
+        ("n_records", C.c_uint32),
+        ("route_count", C.c_uint32 * 3),
+        ("_pad", C.c_uint32),
+        ("route_bytes", (C.c_uint64 * 2) * 3),
+        ("out_bytes", C.c_uint64 * 2),
+    ]
+
+
+assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 96
 assert C.sizeof(cs_op) == 284, C.sizeof(cs_op)
 assert C.sizeof(cs_result) == 8
 assert C.sizeof(cs_cap2) == 4

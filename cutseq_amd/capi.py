@@ -18,6 +18,7 @@ EXPORTS = (
     "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_device_pipelined", "cs_join", "cs_trim_batch", "cs_sync",
     "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_kernel_time_totals", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
     "cs_free_device", "cs_copy_to_device", "cs_copy_to_host",
+    "cs_text_create", "cs_text_destroy", "cs_text_submit", "cs_text_wait", "cs_text_fetch",
 )
 
 
@@ -93,6 +94,17 @@ def load() -> C.CDLL:
     L.cs_copy_to_device.argtypes = [i32, vp, vp, C.c_size_t]
     L.cs_copy_to_host.restype = i32
     L.cs_copy_to_host.argtypes = [i32, vp, vp, C.c_size_t]
+    u64 = C.c_uint64
+    L.cs_text_create.restype = i32
+    L.cs_text_create.argtypes = [vp, C.POINTER(abi.cs_text_params), u32, u64, u32, u32, C.POINTER(vp)]
+    L.cs_text_destroy.restype = None
+    L.cs_text_destroy.argtypes = [vp]
+    L.cs_text_submit.restype = i32
+    L.cs_text_submit.argtypes = [vp, u32, vp, u64, vp, u64, u32]
+    L.cs_text_wait.restype = i32
+    L.cs_text_wait.argtypes = [vp, u32, C.POINTER(abi.cs_text_result)]
+    L.cs_text_fetch.restype = i32
+    L.cs_text_fetch.argtypes = [vp, u32, vp, vp]
     if L.cs_abi_version() != abi.CS_ABI_VERSION:
         raise HipUnavailable(f"ABI mismatch: library {L.cs_abi_version()} vs python {abi.CS_ABI_VERSION}")
     _lib = L

@@ -12,6 +12,7 @@
 
 #include "../../include/cutseq_hip.h"
 #include "trim_kernel.hip.inc"
+#include "text_kernels.hip.inc"
 
 namespace {
 
@@ -817,6 +818,316 @@ int cs_copy_to_device(int device, void *dst, const void *src, size_t bytes) {
 int cs_copy_to_host(int device, void *dst, const void *src, size_t bytes) {
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return CS_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================
+// Text path (include/cutseq_hip.h, "text path"): upload -> record index -> rows -> trimming kernels -> output text
+// =====================================================================================================
+
+namespace {
+
+struct TextSlot {
+  uint8_t *d_text[2] = {nullptr, nullptr};
+  uint32_t *d_nl[2] = {nullptr, nullptr};
+  cstext::Rec *d_rec[2] = {nullptr, nullptr};
+  uint32_t *d_idr[2] = {nullptr, nullptr};
+  uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
+  uint16_t *d_len[2] = {nullptr, nullptr};
+  cs_result *d_res[2] = {nullptr, nullptr};
+  cs_cap2 *d_cap2 = nullptr;
+  uint32_t *d_dst[2] = {nullptr, nullptr};
+  uint8_t *d_out[2] = {nullptr, nullptr};
+  uint32_t *d_blk = nullptr;              // block sums of the newline passes (per mate) and of the format passes
+  unsigned long long *d_totals = nullptr;  // [2] line totals, [6] format column sums
+  cstext::TextMeta *d_meta = nullptr;
+  cstext::TextMeta *h_meta = nullptr;      // pinned
+  hipEvent_t uploaded = nullptr, formatted = nullptr, fetched = nullptr;
+  uint32_t n = 0;
+  bool busy = false, waited = false;
+};
+
+}  // namespace
+
+struct cs_text {
+  cs_engine *eng = nullptr;
+  cstext::TextParams tp;
+  uint64_t max_text = 0, out_cap = 0;
+  uint32_t max_records = 0, stride = 0, max_tag = 0;
+  uint32_t seg_blocks = 0, fmt_blocks = 0;
+  bool needs_cap2 = false;
+  hipStream_t h2d = nullptr, d2h = nullptr;
+  std::vector<TextSlot> slots;
+};
+
+namespace {
+
+__global__ void text_init_meta(cstext::TextMeta *m) {
+  if (threadIdx.x == 0) {
+    memset(m, 0, sizeof *m);
+    m->err = ~0ull;
+  }
+}
+
+void free_text(cs_text *t) {
+  if (!t) return;
+  if (t->eng) (void)hipSetDevice(t->eng->device);
+  for (TextSlot &s : t->slots) {
+    if (s.busy && s.formatted) (void)hipEventSynchronize(s.formatted);
+    for (int m = 0; m < 2; ++m)
+      for (void *p : {(void *)s.d_text[m], (void *)s.d_nl[m], (void *)s.d_rec[m], (void *)s.d_idr[m], (void *)s.d_seq[m],
+                      (void *)s.d_qual[m], (void *)s.d_len[m], (void *)s.d_res[m], (void *)s.d_dst[m], (void *)s.d_out[m]})
+        if (p) (void)hipFree(p);
+    for (void *p : {(void *)s.d_cap2, (void *)s.d_blk, (void *)s.d_totals, (void *)s.d_meta})
+      if (p) (void)hipFree(p);
+    if (s.h_meta) (void)hipHostFree(s.h_meta);
+    for (hipEvent_t ev : {s.uploaded, s.formatted, s.fetched})
+      if (ev) (void)hipEventDestroy(ev);
+  }
+  if (t->h2d) (void)hipStreamDestroy(t->h2d);
+  if (t->d2h) (void)hipStreamDestroy(t->d2h);
+  delete t;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cs_text_destroy(cs_text *t) { free_text(t); }
+
+int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slots, uint64_t max_text_bytes,
+                   uint32_t max_records, uint32_t stride, cs_text **out) {
+  if (!out) return fail(CS_ERR_ARG, "out is null");
+  *out = nullptr;
+  if (!eng || !params) return fail(CS_ERR_ARG, "null engine or params");
+  if (!n_slots || !max_records || !max_text_bytes) return fail(CS_ERR_ARG, "slots, records and text bytes must be positive");
+  if (stride == 0 || stride % 4 || stride > CS_MAX_STRIDE)
+    return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);
+  const uint64_t out_cap = max_text_bytes + (uint64_t)max_records * (params->max_tag + 8u) + 64u;
+  if (max_text_bytes >= (1ull << 30) || out_cap >= (1ull << 30))
+    return fail(CS_ERR_ARG, "a batch is limited to 1 GiB of text per mate (%llu requested)", (unsigned long long)max_text_bytes);
+  cs_text *t = new (std::nothrow) cs_text();
+  if (!t) return fail(CS_ERR_NOMEM, "out of memory");
+  t->eng = eng;
+  t->max_text = max_text_bytes;
+  t->out_cap = out_cap;
+  t->max_records = max_records;
+  t->stride = stride;
+  t->max_tag = params->max_tag;
+  memset(&t->tp, 0, sizeof t->tp);
+  t->tp.paired = eng->paired ? 1 : 0;
+  t->tp.has_umi = params->has_umi ? 1 : 0;
+  t->tp.untrimmed_filter = params->untrimmed_filter ? 1 : 0;
+  t->tp.reverse_complement = params->reverse_complement ? 1 : 0;
+  t->tp.flag_too_short = CS_F_TOO_SHORT;
+  t->tp.flag_untrimmed = CS_F_UNTRIMMED;
+  const char *const *suf[2] = {params->suffix1, params->suffix2};
+  for (int m = 0; m < 2; ++m)
+    for (int k = 0; k < 2; ++k) {
+      const char *lit = suf[m][k];
+      const size_t len = lit ? strlen(lit) : 0;
+      if (len > cstext::kSuffixMax) {
+        delete t;
+        return fail(CS_ERR_ARG, "name suffix literal longer than %u bytes", cstext::kSuffixMax);
+      }
+      t->tp.suffix_len[m][k] = (uint8_t)len;
+      if (len) memcpy(t->tp.suffix[m][k], lit, len);
+    }
+  // a second capture exists only in single-end chains (cs_cap2)
+  t->needs_cap2 = !eng->paired && params->has_umi;
+  t->seg_blocks = (uint32_t)((max_text_bytes + cstext::kSeg - 1) / cstext::kSeg);
+  t->fmt_blocks = (max_records + 255u) / 256u;
+#define TXT_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      fail(CS_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      free_text(t);                                                                         \
+      return CS_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+  TXT_TRY(hipSetDevice(eng->device));
+  TXT_TRY(hipStreamCreateWithFlags(&t->h2d, hipStreamNonBlocking));
+  TXT_TRY(hipStreamCreateWithFlags(&t->d2h, hipStreamNonBlocking));
+  t->slots.resize(n_slots);
+  const int mates = eng->paired ? 2 : 1;
+  const size_t rows = (size_t)max_records * stride;
+  for (TextSlot &s : t->slots) {
+    for (int m = 0; m < mates; ++m) {
+      TXT_TRY(hipMalloc(&s.d_text[m], max_text_bytes + 64));
+      TXT_TRY(hipMemset(s.d_text[m], 0, max_text_bytes + 64));
+      // (zeroed: a batch that is rejected half-way leaves some of these unwritten, and whatever a later kernel of
+      // that batch still reads through them must stay inside the allocations)
+      TXT_TRY(hipMalloc(&s.d_nl[m], ((size_t)max_records * 4 + 8) * sizeof(uint32_t)));
+      TXT_TRY(hipMemset(s.d_nl[m], 0, ((size_t)max_records * 4 + 8) * sizeof(uint32_t)));
+      TXT_TRY(hipMalloc(&s.d_rec[m], (size_t)max_records * sizeof(cstext::Rec)));
+      TXT_TRY(hipMemset(s.d_rec[m], 0, (size_t)max_records * sizeof(cstext::Rec)));
+      TXT_TRY(hipMalloc(&s.d_idr[m], (size_t)max_records * sizeof(uint32_t)));
+      TXT_TRY(hipMemset(s.d_idr[m], 0, (size_t)max_records * sizeof(uint32_t)));
+      TXT_TRY(hipMalloc(&s.d_seq[m], rows));
+      TXT_TRY(hipMalloc(&s.d_qual[m], rows));
+      TXT_TRY(hipMalloc(&s.d_len[m], (size_t)max_records * sizeof(uint16_t)));
+      TXT_TRY(hipMalloc(&s.d_res[m], (size_t)max_records * sizeof(cs_result)));
+      TXT_TRY(hipMalloc(&s.d_dst[m], (size_t)max_records * sizeof(uint32_t)));
+      TXT_TRY(hipMalloc(&s.d_out[m], out_cap));
+    }
+    if (t->needs_cap2) TXT_TRY(hipMalloc(&s.d_cap2, (size_t)max_records * sizeof(cs_cap2)));
+    const size_t blk = (size_t)2 * (t->seg_blocks + 1) + (size_t)6 * (t->fmt_blocks + 1);
+    TXT_TRY(hipMalloc(&s.d_blk, blk * sizeof(uint32_t)));
+    TXT_TRY(hipMalloc(&s.d_totals, 8 * sizeof(unsigned long long)));
+    TXT_TRY(hipMalloc(&s.d_meta, sizeof(cstext::TextMeta)));
+    TXT_TRY(hipHostMalloc(&s.h_meta, sizeof(cstext::TextMeta), hipHostMallocPortable));
+    TXT_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    TXT_TRY(hipEventCreateWithFlags(&s.formatted, hipEventDisableTiming));
+    TXT_TRY(hipEventCreateWithFlags(&s.fetched, hipEventDisableTiming));
+  }
+#undef TXT_TRY
+  *out = t;
+  return CS_OK;
+}
+
+int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1, const void *text2, uint64_t bytes2,
+                   uint32_t n_records) {
+  if (!t || !text1) return fail(CS_ERR_ARG, "null text engine or text");
+  if (slot >= t->slots.size()) return fail(CS_ERR_ARG, "slot %u out of range", slot);
+  cs_engine *eng = t->eng;
+  if ((text2 != nullptr) != eng->paired) return fail(CS_ERR_ARG, "plan is %s-end", eng->paired ? "paired" : "single");
+  if (bytes1 > t->max_text || bytes2 > t->max_text || n_records > t->max_records)
+    return fail(CS_ERR_ARG, "batch of %u records, %llu / %llu bytes exceeds the slot (%u records, %llu bytes)", n_records,
+                (unsigned long long)bytes1, (unsigned long long)bytes2, t->max_records, (unsigned long long)t->max_text);
+  TextSlot &s = t->slots[slot];
+  if (s.busy) return fail(CS_ERR_STATE, "slot %u still in flight: cs_text_wait + cs_text_fetch first", slot);
+  HIP_TRY(hipSetDevice(eng->device));
+  const int mates = eng->paired ? 2 : 1;
+  const void *src[2] = {text1, text2};
+  const uint64_t bytes[2] = {bytes1, bytes2};
+  for (int m = 0; m < mates; ++m)
+    if (n_records && !bytes[m]) return fail(CS_ERR_ARG, "mate %d: %u records in 0 bytes of text", m + 1, n_records);
+  s.n = n_records;
+  s.waited = false;
+  hipStream_t st = eng->stream, rs = eng->resolve_stream;
+  for (int m = 0; m < mates; ++m)
+    if (bytes[m]) HIP_TRY(hipMemcpyAsync(s.d_text[m], src[m], bytes[m], hipMemcpyHostToDevice, t->h2d));
+  HIP_TRY(hipEventRecord(s.uploaded, t->h2d));
+  HIP_TRY(hipStreamWaitEvent(st, s.uploaded, 0));
+  hipLaunchKernelGGL(text_init_meta, dim3(1), dim3(64), 0, st, s.d_meta);
+  uint32_t *blk_nl[2] = {s.d_blk, s.d_blk + t->seg_blocks + 1};
+  uint32_t *blk_fmt = s.d_blk + 2 * (t->seg_blocks + 1);
+  if (n_records) {
+    for (int m = 0; m < mates; ++m) {
+      const uint32_t nb = (uint32_t)((bytes[m] + cstext::kSeg - 1) / cstext::kSeg);
+      hipLaunchKernelGGL(cstext::text_count_nl, dim3(nb), dim3(cstext::kSegThreads), 0, st, s.d_text[m], (uint32_t)bytes[m],
+                         blk_nl[m]);
+      hipLaunchKernelGGL(cstext::text_scan_blocks, dim3(1), dim3(1024), 0, st, blk_nl[m], nb, 1u, s.d_totals + m);
+      hipLaunchKernelGGL(cstext::text_write_nl, dim3(nb), dim3(cstext::kSegThreads), 0, st, s.d_text[m], (uint32_t)bytes[m],
+                         blk_nl[m], s.d_totals + m, 4u * n_records, s.d_nl[m], s.d_meta, m);
+      hipLaunchKernelGGL(cstext::text_parse_records, dim3((n_records + 255u) / 256u), dim3(256), 0, st, s.d_text[m],
+                         s.d_nl[m], n_records, t->stride, t->tp, m, s.d_rec[m], s.d_idr[m], s.d_len[m], s.d_meta);
+    }
+    if (mates == 2)
+      hipLaunchKernelGGL(cstext::text_check_pairs, dim3((n_records + 255u) / 256u), dim3(256), 0, st, s.d_text[0], s.d_rec[0],
+                         s.d_text[1], s.d_rec[1], n_records, s.d_meta);
+    for (int m = 0; m < mates; ++m) {
+      const unsigned long long dwords = (unsigned long long)n_records * (t->stride / 4) * 2ull;
+      const uint32_t grid = (uint32_t)((dwords + 255ull) / 256ull > 65536ull ? 65536ull : (dwords + 255ull) / 256ull);
+      hipLaunchKernelGGL(cstext::text_restride, dim3(grid), dim3(256), 0, st, s.d_text[m], s.d_rec[m], n_records, t->stride / 4,
+                         reinterpret_cast<uint32_t *>(s.d_seq[m]), reinterpret_cast<uint32_t *>(s.d_qual[m]));
+    }
+    HIP_TRY(hipGetLastError());
+    cs_reads rd[2];
+    for (int m = 0; m < mates; ++m) {
+      rd[m].seq = s.d_seq[m];
+      rd[m].qual = s.d_qual[m];
+      rd[m].len = s.d_len[m];
+      rd[m].out = s.d_res[m];
+      rd[m].cap2 = (m == 0) ? s.d_cap2 : nullptr;
+      rd[m].bc = nullptr;
+    }
+    int rc = launch(eng, st, rs, &rd[0], mates == 2 ? &rd[1] : nullptr, n_records, t->stride, false);
+    if (rc) return rc;
+    cstext::FormatArgs fa;
+    memset(&fa, 0, sizeof fa);
+    for (int m = 0; m < mates; ++m) {
+      fa.text[m] = s.d_text[m];
+      fa.rec[m] = s.d_rec[m];
+      fa.idr[m] = s.d_idr[m];
+      fa.seq[m] = s.d_seq[m];
+      fa.qual[m] = s.d_qual[m];
+      fa.res[m] = s.d_res[m];
+      fa.dst[m] = s.d_dst[m];
+      fa.out[m] = s.d_out[m];
+    }
+    fa.cap2 = s.d_cap2;
+    fa.n = n_records;
+    fa.stride = t->stride;
+    fa.blk = blk_fmt;
+    fa.totals = s.d_totals + 2;
+    fa.meta = s.d_meta;
+    const uint32_t fb = (n_records + 255u) / 256u;
+    hipLaunchKernelGGL(cstext::format_sizes, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+    hipLaunchKernelGGL(cstext::text_scan_blocks, dim3(1), dim3(1024), 0, rs, blk_fmt, fb, 6u, fa.totals);
+    hipLaunchKernelGGL(cstext::format_offsets, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+    const unsigned long long items = (unsigned long long)n_records * mates;
+    const unsigned long long want = (items * 32ull + 255ull) / 256ull;
+    hipLaunchKernelGGL(cstext::format_copy, dim3((uint32_t)(want > 32768ull ? 32768ull : want)), dim3(256), 0, rs, fa, t->tp);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipEventRecord(s.fetched, st));  // order the resolve stream behind the (empty) batch's meta
+    HIP_TRY(hipStreamWaitEvent(rs, s.fetched, 0));
+  }
+  HIP_TRY(hipMemcpyAsync(s.h_meta, s.d_meta, sizeof(cstext::TextMeta), hipMemcpyDeviceToHost, rs));
+  HIP_TRY(hipEventRecord(s.formatted, rs));
+  s.busy = true;
+  return CS_OK;
+}
+
+int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
+  if (!t || !res) return fail(CS_ERR_ARG, "null argument");
+  if (slot >= t->slots.size()) return fail(CS_ERR_ARG, "slot %u out of range", slot);
+  TextSlot &s = t->slots[slot];
+  if (!s.busy) return fail(CS_ERR_STATE, "slot %u holds no batch", slot);
+  HIP_TRY(hipSetDevice(t->eng->device));
+  HIP_TRY(hipEventSynchronize(s.formatted));
+  memset(res, 0, sizeof *res);
+  const cstext::TextMeta &m = *s.h_meta;
+  res->n_records = s.n;
+  res->max_len = m.max_len;
+  if (m.err != ~0ull) {
+    res->error = (int32_t)(m.err & 0xffu);
+    res->error_record = (uint32_t)(m.err >> 8);
+  }
+  for (int q = 0; q < 3; ++q) {
+    res->route_count[q] = m.route_count[q];
+    for (int k = 0; k < 2; ++k) res->route_bytes[q][k] = m.route_bytes[q][k];
+  }
+  res->out_bytes[0] = m.out_bytes[0];
+  res->out_bytes[1] = m.out_bytes[1];
+  if (res->error) {  // nothing to fetch: the slot is free again
+    res->out_bytes[0] = res->out_bytes[1] = 0;
+    s.busy = false;
+  }
+  s.waited = true;
+  return CS_OK;
+}
+
+int cs_text_fetch(cs_text *t, uint32_t slot, void *dst1, void *dst2) {
+  if (!t) return fail(CS_ERR_ARG, "null text engine");
+  if (slot >= t->slots.size()) return fail(CS_ERR_ARG, "slot %u out of range", slot);
+  TextSlot &s = t->slots[slot];
+  if (!s.busy || !s.waited) return fail(CS_ERR_STATE, "slot %u: cs_text_wait first", slot);
+  HIP_TRY(hipSetDevice(t->eng->device));
+  void *dst[2] = {dst1, dst2};
+  for (int m = 0; m < (t->eng->paired ? 2 : 1); ++m) {
+    const size_t bytes = (size_t)s.h_meta->out_bytes[m];
+    if (!bytes) continue;
+    if (!dst[m]) return fail(CS_ERR_ARG, "mate %d: %zu bytes of output and no buffer", m + 1, bytes);
+    HIP_TRY(hipMemcpyAsync(dst[m], s.d_out[m], bytes, hipMemcpyDeviceToHost, t->d2h));
+  }
+  HIP_TRY(hipEventRecord(s.fetched, t->d2h));
+  HIP_TRY(hipEventSynchronize(s.fetched));
+  s.busy = false;
   return CS_OK;
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 3
+#define CS_ABI_VERSION 4
 #define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
 #define CS_MAX_OPS 24      /* longest per-mate op chain                           */
 #define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
@@ -250,6 +250,64 @@ int cs_last_kernel_split_ms(cs_engine *eng, float ms[2]);
 /* Sums of those event-measured durations over every cs_trim_device / cs_trim_device_pipelined call since
  * the last reset (*calls of them): the per-kernel averages bench.py reports.  Waits for the calls in flight. */
 int cs_kernel_time_totals(cs_engine *eng, uint32_t *calls, float ms[2], int reset);
+
+/* ---- text path: raw FASTQ text in, finished FASTQ text out -------------------------------
+ * Replaces what dnaio / cutadapt.files do around the modifier loop for the reference (record parsing in
+ * runner.run's reader, cutseq/run.py:434-441, 751-758; SuffixRemover / Renamer / PairedEndRenamer string work,
+ * run.py:330, 378, 537-542, 642-645; TooShort -> IsUntrimmedAny -> sink routing and record formatting,
+ * run.py:446-471, 760-793): the host hands over record-aligned text blocks exactly as they come out of the file
+ * or the inflate threads, the device finds the records, runs the trimming kernels on them and writes the output
+ * records of the three routes; the host only reads / inflates and deflates / writes.
+ *
+ * A batch is `n_records` complete 4-line records per mate ('\n' or '\r\n' line ends; the last line may lack
+ * its line end).  Output per mate: the records of route 0 (trimmed), 1 (too short), 2 (untrimmed) back to back,
+ * each route in input order, each record as  @<id>[_<captured bases>]\n<seq[start:stop]>\n+\n<qual[start:stop]>\n.
+ * Errors are reported the way the reference's reader would raise them (cs_text_result.error), never ignored. */
+enum {
+  CS_TEXT_OK = 0,
+  CS_TEXT_ERR_MALFORMED = 1,   /* no '@' / '+' line, sequence and quality lengths differ: record `error_record` */
+  CS_TEXT_ERR_TOO_LONG = 2,    /* a read is longer than the row stride: rebuild with `max_len` and resubmit    */
+  CS_TEXT_ERR_IDS_DIFFER = 3,  /* PairedEndRenamer: "Input read IDs not identical" at record `error_record`    */
+  CS_TEXT_ERR_LINE_COUNT = 4   /* the text does not hold 4 * n_records lines                                   */
+};
+
+typedef struct cs_text_params {
+  uint8_t has_umi;            /* Renamer template carries the captures: {id}_{cut_prefix}{cut_suffix}           */
+  uint8_t untrimmed_filter;   /* IsUntrimmedAny filter installed (run.py:453-467, 771-784)                      */
+  uint8_t reverse_complement; /* single-end --auto-rc on a '-' library (run.py:420-426)                         */
+  uint8_t _pad;
+  uint32_t max_tag;           /* most bytes a record name can gain: 1 + the plan's capture lengths (0 = no UMI) */
+  const char *suffix1[2];     /* SuffixRemover literals of mate 1, applied in order (NULL = none)               */
+  const char *suffix2[2];
+} cs_text_params;
+
+typedef struct cs_text_result {
+  int32_t error;              /* CS_TEXT_*                                                                      */
+  uint32_t error_record;      /* first offending record of the batch                                            */
+  uint32_t max_len;           /* longest read of the batch                                                      */
+  uint32_t n_records;
+  uint32_t route_count[3];    /* records (pairs) per route                                                      */
+  uint32_t _pad;
+  uint64_t route_bytes[3][2]; /* [route][mate]                                                                  */
+  uint64_t out_bytes[2];      /* per mate: sum over the routes = what cs_text_fetch copies                      */
+} cs_text_result;
+
+typedef struct cs_text cs_text;
+
+/* `n_slots` batches in flight, each up to `max_text_bytes` of text per mate and `max_records` records, rows of
+ * `stride` bytes (multiple of 4, <= CS_MAX_STRIDE).  Uses the engine's plan, streams and statistics block. */
+int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slots, uint64_t max_text_bytes,
+                   uint32_t max_records, uint32_t stride, cs_text **out);
+void cs_text_destroy(cs_text *t);
+/* Asynchronous: upload (text1 / text2: host memory, pinned for true overlap; they must stay untouched until
+ * cs_text_wait returns), record index, trimming kernels, output formatting.  text2 == NULL for single-end. */
+int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1, const void *text2, uint64_t bytes2,
+                   uint32_t n_records);
+/* Blocks until the slot's batch is formatted on the device; sizes and errors in *res. */
+int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res);
+/* Copies the output text (res->out_bytes[m] bytes per mate) into the caller's buffers and blocks until it is
+ * there; the slot is free for the next cs_text_submit afterwards.  dst2 == NULL for single-end. */
+int cs_text_fetch(cs_text *t, uint32_t slot, void *dst1, void *dst2);
 
 void *cs_alloc_pinned(size_t bytes);
 void cs_free_pinned(void *p);

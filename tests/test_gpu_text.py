@@ -1,0 +1,176 @@
+"""Text path (``cs_text_*``): FASTQ text in, finished FASTQ text out, all on the device -- against the CPU oracle's
+results formatted by the Python record logic (``hostfmt``), byte for byte and route by route.
+
+Reference surface replaced: dnaio's record reader / writer and the name modifiers around cutadapt's modifier loop
+(cutseq/run.py:330, 378, 434-441, 537-542, 642-645, 751-758, 785-794).  Edge cases are the ones ``tests/test_host_io.py``
+holds for the host parser: CRLF, no final newline, mismatched ids, malformed and truncated records.
+"""
+import numpy as np
+import pytest
+
+from cutseq_amd import abi, plan as planmod, synth, textpath
+from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
+from cutseq_amd.engine import TrimEngine
+
+import util
+from test_oracle import CHAIN_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def fastq_text(names, seq, qual, lens, eol=b"\n", final_newline=True):
+    recs = []
+    for i, name in enumerate(names):
+        n = int(lens[i])
+        recs.append(b"@" + name + eol + seq[i, :n].tobytes() + eol + b"+" + eol + qual[i, :n].tobytes() + eol)
+    body = b"".join(recs)
+    return body if final_newline else body[: -len(eol)]
+
+
+def expected_streams(tp, batch, names1, names2):
+    (o1, cap2, _), m2 = util.oracle_run(tp, batch, threads=8)
+    recs = util.format_batch(tp, batch, names1, names2, o1, cap2, m2[0] if m2 else None)
+    streams = [[b"", b""] for _ in range(3)]
+    counts = [0, 0, 0]
+    for route, r1, r2 in recs:
+        streams[route][0] += r1
+        if r2 is not None:
+            streams[route][1] += r2
+        counts[route] += 1
+    return streams, counts
+
+
+def run_text(tp, text1, text2, n, stride, max_records=None):
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=2, max_text_bytes=max(len(text1), len(text2 or b""), 1) + 1024,
+                                 max_records=max_records or max(n, 1), stride=stride) as te:
+            return te.run(text1, n, text2)
+
+
+@pytest.mark.parametrize("name,flags,paired", [c for c in CHAIN_CASES if "shortcut" not in c[1]])
+def test_text_path_equals_oracle_plus_record_logic(name, flags, paired):
+    scheme = BUILDIN_ADAPTERS.get(name, name)
+    st = planmod.CutadaptConfig()
+    for k, v in flags.items():
+        setattr(st, k, v)
+    n = 3000
+    batch = synth.generate_pairs(n, 150, scheme, seed=5, chunk_index=len(name), single_end=not paired,
+                                 poly_fraction=0.1, art5_fraction=0.02)
+    rng = np.random.default_rng(7)
+    cut = rng.random(n) < 0.1  # ragged lengths, some empty
+    batch.len1[cut] = rng.integers(0, 150, size=int(cut.sum())).astype(np.uint16)
+    if paired:
+        batch.len2[cut] = rng.integers(0, 150, size=int(cut.sum())).astype(np.uint16)
+    tp = util.compile_plan(scheme, st, paired, untrimmed_requested="INLINE" in name)
+    names1 = [f"SIM:{i}/1 1:N:0:X".encode() if i % 3 else f"SIM:{i}.1".encode() for i in range(n)]
+    names2 = [f"SIM:{i}/2 2:N:0:X".encode() if i % 3 else f"SIM:{i}.2".encode() for i in range(n)] if paired else None
+    want, want_counts = expected_streams(tp, batch, names1, names2)
+    text1 = fastq_text(names1, batch.seq1, batch.qual1, batch.len1)
+    text2 = fastq_text(names2, batch.seq2, batch.qual2, batch.len2) if paired else None
+    got, counts = run_text(tp, text1, text2, n, batch.stride)
+    assert counts == want_counts
+    for route in range(3):
+        for m in range(2 if paired else 1):
+            assert got[route][m] == want[route][m], (textpath.ROUTES[route], m)
+
+
+@pytest.mark.parametrize("eol,final_newline", [(b"\n", False), (b"\r\n", True), (b"\r\n", False)])
+def test_text_path_line_endings(eol, final_newline):
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    scheme = BUILDIN_ADAPTERS["TAKARAV3"]
+    tp = util.compile_plan(scheme, st, True)
+    n = 700
+    batch = synth.generate_pairs(n, 150, scheme, seed=9)
+    names1 = [s.encode() for s in synth.headers(n, 1)]
+    names2 = [s.encode() for s in synth.headers(n, 2)]
+    want, want_counts = expected_streams(tp, batch, names1, names2)
+    text1 = fastq_text(names1, batch.seq1, batch.qual1, batch.len1, eol, final_newline)
+    text2 = fastq_text(names2, batch.seq2, batch.qual2, batch.len2, eol, True)
+    got, counts = run_text(tp, text1, text2, n, batch.stride)
+    assert counts == want_counts and got == want
+
+
+def test_text_path_fixture_and_several_batches_in_flight():
+    """The reference's own reads (fixture10k) in batches of 2 500 through three slots; different batch sizes."""
+    rec1 = util.read_fastq_gz(util.GOLDEN / "fixture10k_R1.fq.gz")
+    rec2 = util.read_fastq_gz(util.GOLDEN / "fixture10k_R2.fq.gz")
+    batch = util.batch_from_records(rec1, rec2)
+    st = planmod.CutadaptConfig()
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    names1, names2 = [r[0] for r in rec1], [r[0] for r in rec2]
+    want, want_counts = expected_streams(tp, batch, names1, names2)
+    sizes = [2500, 2500, 1, 3999, 1000]
+    texts, lo = [], 0
+    for size in sizes:
+        hi = lo + size
+        texts.append((fastq_text(names1[lo:hi], batch.seq1[lo:hi], batch.qual1[lo:hi], batch.len1[lo:hi]),
+                      fastq_text(names2[lo:hi], batch.seq2[lo:hi], batch.qual2[lo:hi], batch.len2[lo:hi]), size))
+        lo = hi
+    assert lo == len(rec1)
+    got = [[b"", b""] for _ in range(3)]
+    counts = [0, 0, 0]
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=3, max_text_bytes=max(len(t[0]) for t in texts) + 4096, max_records=4000,
+                                 stride=batch.stride) as te:
+            pending = []
+
+            def finish(slot):
+                res = te.wait(slot)
+                out = [np.empty(max(int(res.out_bytes[m]), 1), dtype=np.uint8) for m in range(2)]
+                te.fetch(slot, out[0], out[1])
+                part = textpath.split_routes(res, out, True)
+                for route in range(3):
+                    counts[route] += int(res.route_count[route])
+                    for m in range(2):
+                        got[route][m] += part[route][m]
+
+            for k, (t1, t2, size) in enumerate(texts):
+                if len(pending) == 3:
+                    finish(pending.pop(0))
+                te.submit(k % 3, t1, len(t1), t2, len(t2), size)
+                pending.append(k % 3)
+            while pending:
+                finish(pending.pop(0))
+            st1, st2 = eng.stats()
+    assert counts == want_counts and sum(counts) == len(rec1)
+    assert got == want
+    assert int(st1.n_reads) == len(rec1) == int(st2.n_reads)
+
+
+def test_text_path_errors_are_the_readers_errors():
+    st = planmod.CutadaptConfig()
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    good1 = b"@r1 1\nACGTACGTAC\n+\nIIIIIIIIII\n@r2 1\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    good2 = b"@r1 2\nACGTACGTAC\n+\nIIIIIIIIII\n@r2 2\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=1, max_text_bytes=4096, max_records=16, stride=12) as te:
+            streams, counts = te.run(good1, 2, good2)
+            assert sum(counts) == 2
+            # mate ids differ in the second record (PairedEndRenamer: "Input read IDs not identical")
+            with pytest.raises(textpath.TextFormatError) as e:
+                te.run(good1, 2, good2.replace(b"@r2 2", b"@rX 2"))
+            assert e.value.code == abi.CS_TEXT_ERR_IDS_DIFFER and e.value.record == 1
+            # ... but a trailing /1 vs /2 (or 1 vs 2) is the same id
+            te.run(good1.replace(b"@r2 1", b"@r2/1 x"), 2, good2.replace(b"@r2 2", b"@r2/2 y"))
+            # no '@', no '+', lengths differ
+            for bad in (good1.replace(b"@r2", b"r2"), good1.replace(b"+\nIIIIIIIIII\n@r2", b"-\nIIIIIIIIII\n@r2"),
+                        good1[:-3] + b"\n"):
+                with pytest.raises(textpath.TextFormatError) as e:
+                    te.run(bad, 2, good2)
+                assert e.value.code == abi.CS_TEXT_ERR_MALFORMED
+            # a truncated block: fewer lines than announced
+            with pytest.raises(textpath.TextFormatError) as e:
+                te.run(good1[: len(good1) // 2 + 3], 2, good2)
+            assert e.value.code in (abi.CS_TEXT_ERR_LINE_COUNT, abi.CS_TEXT_ERR_MALFORMED)
+            # a read longer than the rows: the caller is told how long, nothing is written
+            long1 = b"@r1 1\n" + b"A" * 40 + b"\n+\n" + b"I" * 40 + b"\n"
+            with pytest.raises(textpath.ReadLongerThanStride) as e:
+                te.run(long1, 1, b"@r1 2\nACGT\n+\nIIII\n")
+            assert e.value.longest == 40
+            # the engine is still usable afterwards
+            streams2, counts2 = te.run(good1, 2, good2)
+            assert streams2 == streams and counts2 == counts
+            # empty batch
+            streams3, counts3 = te.run(b"", 0, b"")
+            assert counts3 == [0, 0, 0] and streams3 == [[b"", b""]] * 3
