@@ -52,7 +52,7 @@ def build_host(force: bool = False) -> Path:
     """Host-only helpers (synthetic generator): plain gcc, no GPU toolchain involved."""
     if not force and HOST_OUT.exists() and HOST_OUT.stat().st_mtime >= HOST_SRC.stat().st_mtime:
         return HOST_OUT
-    cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-o", str(HOST_OUT), str(HOST_SRC), "-lpthread"]
+    cmd = ["gcc", "-O3", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-o", str(HOST_OUT), str(HOST_SRC), "-lpthread"]
     subprocess.run(cmd, check=True)
     return HOST_OUT
 

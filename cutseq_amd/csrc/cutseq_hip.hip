@@ -262,7 +262,7 @@ int harvest(cs_engine *eng, Lane &ln) {
 // resolve stream for the pipelined form: the next call's scan kernel then runs beside this call's resolve
 // kernel, whose few latency-bound waves fit into what the scan kernel leaves idle).
 int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_reads *r1, const cs_reads *r2,
-           uint32_t n_reads, uint32_t stride, bool time_it) {
+           uint32_t n_reads, uint32_t stride, bool time_it, const unsigned long long *gate = nullptr) {
   Geometry g[2];
   for (int mode = 0; mode < 2; ++mode) {
     int rc = geometry_for(eng, stride, mode, g[mode]);
@@ -317,6 +317,7 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   a.tile_counter = ln.d_counters;
   a.n_table_ops = eng->n_table_ops;
   a.batch_knob = eng->knob_batch;
+  a.gate = gate;
   for (int mode = 0; mode < 2; ++mode)
     if (g[mode].lds_bytes > eng->max_dynamic_lds[mode]) {
       HIP_TRY(hipFuncSetAttribute(kernel_for(eng, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g[mode].lds_bytes));
@@ -1045,7 +1046,7 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
       rd[m].cap2 = (m == 0) ? s.d_cap2 : nullptr;
       rd[m].bc = nullptr;
     }
-    int rc = launch(eng, st, rs, &rd[0], mates == 2 ? &rd[1] : nullptr, n_records, t->stride, false);
+    int rc = launch(eng, st, rs, &rd[0], mates == 2 ? &rd[1] : nullptr, n_records, t->stride, false, &s.d_meta->err);
     if (rc) return rc;
     cstext::FormatArgs fa;
     memset(&fa, 0, sizeof fa);
@@ -1104,6 +1105,8 @@ int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
   }
   res->out_bytes[0] = m.out_bytes[0];
   res->out_bytes[1] = m.out_bytes[1];
+  res->written_bp[0] = m.written_bp[0];
+  res->written_bp[1] = m.written_bp[1];
   if (res->error) {  // nothing to fetch: the slot is free again
     res->out_bytes[0] = res->out_bytes[1] = 0;
     s.busy = false;

@@ -570,3 +570,58 @@ int64_t csh_format_chunk_bins(const csh_format_params *fp, int64_t n, uint32_t s
     for (int m = 0; m < 2; m++) out_len[r][m] = w[r][m] - out[r][m];
   return 0;
 }
+
+/* ===========================================================================================
+ * Text path (cutseq_amd/textpath.py): the host only has to cut the input into blocks of whole
+ * records; the device finds the records inside a block.  Two vectorised passes over the text.
+ * =========================================================================================== */
+
+/* number of '\n' in buf[0, n) */
+#include <immintrin.h>
+__attribute__((target("avx2"))) static int64_t count_newlines_avx2(const uint8_t *buf, int64_t n) {
+  const __m256i nl = _mm256_set1_epi8('\n');
+  int64_t total = 0, i = 0;
+  while (i + 32 <= n) {
+    /* byte counters: at most 255 rounds before they are folded into 64-bit sums */
+    __m256i acc = _mm256_setzero_si256();
+    int64_t rounds = (n - i) / 32;
+    if (rounds > 255) rounds = 255;
+    for (int64_t r = 0; r < rounds; r++, i += 32)
+      acc = _mm256_sub_epi8(acc, _mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(buf + i)), nl));
+    const __m256i sad = _mm256_sad_epu8(acc, _mm256_setzero_si256());
+    total += _mm256_extract_epi64(sad, 0) + _mm256_extract_epi64(sad, 1) + _mm256_extract_epi64(sad, 2) +
+             _mm256_extract_epi64(sad, 3);
+  }
+  for (; i < n; i++) total += buf[i] == '\n';
+  return total;
+}
+int64_t csh_count_newlines(const uint8_t *buf, int64_t n) {
+  static int have_avx2 = -1;
+  if (have_avx2 < 0) have_avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (have_avx2) return count_newlines_avx2(buf, n);
+  int64_t total = 0;
+  const uint8_t *p = buf, *end = buf + n;
+  while (p < end && (p = (const uint8_t *)memchr(p, '\n', (size_t)(end - p))) != NULL) {
+    total++;
+    p++;
+  }
+  return total;
+}
+
+/* offset just behind the k-th '\n' (k >= 1) of buf[0, n), or -1 when there are fewer */
+int64_t csh_after_kth_newline(const uint8_t *buf, int64_t n, int64_t k) {
+  if (k < 1) return 0;
+  int64_t i = 0;
+  while (i < n) { /* skip whole blocks, then walk the one that holds the k-th newline */
+    int64_t end = i + 65536 < n ? i + 65536 : n;
+    int64_t c = csh_count_newlines(buf + i, end - i);
+    if (c < k) {
+      k -= c;
+      i = end;
+      continue;
+    }
+    for (; i < end; i++)
+      if (buf[i] == '\n' && --k == 0) return i + 1;
+  }
+  return -1;
+}

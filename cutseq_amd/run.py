@@ -315,6 +315,11 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
             logging.warning("-t/--threads ignored: the host thread pool of this process is already running.")
     want = os.environ.get("CUTSEQ_DEVICES")  # e.g. "0,1,2,3"; a device may be listed twice (two engines on it)
     devices = [int(x) for x in want.split(",")] if want else list(range(n_dev))
+    # Text path (default): the device parses the records and formats the output (textio.py / cs_text_*); the host
+    # path below (native parser / formatter in a thread pool) stays for demultiplexing runs and as CUTSEQ_TEXT_PATH=0.
+    if tp.demux is None and os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
+        from . import textio
+        return textio.run_text_pipeline(args, tp, devices, int(os.environ.get("CUTSEQ_CHUNK_READS", textio.CHUNK_READS)))
     chunk_reads = int(os.environ.get("CUTSEQ_CHUNK_READS", fastq.CHUNK_READS))
     paired = tp.paired
     in1 = args.input_file[0]

@@ -1,0 +1,597 @@
+"""Host side of the text path: blocks of whole FASTQ records in, output streams out.
+
+What is left for the host once the device parses and formats (``cs_text_*``, ``textpath.py``): read (or inflate)
+the input, cut it into blocks of exactly ``chunk_reads`` records -- two vectorised passes over the bytes, newline
+count and k-th newline, no per-record work -- and write (or deflate) the finished output text, strictly in input
+order.  Counterpart of ``runner.run(pipeline, Progress(), outfiles)`` with ``make_runner(cores=N)``
+(cutseq/run.py:436, 473, 753, 794): reader, chunk fan-out to workers, ordered merge.
+
+  TextReader    one thread per input file: page cache (several ``pread`` calls at once) or inflate pool -> pinned
+                block buffer -> ``TextBlock(buf, nbytes, n_records)``
+  TextWorker    one thread per GPU: a ``TrimEngine`` + ``TextEngine``, three batches in flight; grows the row stride
+                or the text capacity when a batch needs it
+  run_text_pipeline   pairs the mates' blocks, deals them round-robin, re-orders the results and feeds one
+                ``StreamWriter`` per output file (plain: parallel ``pwrite``; ``.gz``: 4 MB gzip members from the pool)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import queue
+import threading
+import time
+from collections import deque
+from typing import List, Optional
+
+import numpy as np
+
+from . import abi, codec, fastq, report, shard, textpath
+
+CHUNK_READS = 1 << 18
+_BLOCK = 8 << 20          # bytes per pread / per inflate hand-over
+_GZ_PIECE = 4 << 20       # output text per gzip member
+_PWRITE_PIECE = 8 << 20
+
+
+def _host():
+    L = fastq._lib()
+    if not getattr(L, "_text_bound", False):
+        L.csh_count_newlines.restype = C.c_int64
+        L.csh_count_newlines.argtypes = [C.c_void_p, C.c_int64]
+        L.csh_after_kth_newline.restype = C.c_int64
+        L.csh_after_kth_newline.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L._text_bound = True
+    return L
+
+
+class TextBlock:
+    """``n_records`` complete records in ``buf[:nbytes]`` (a pinned arena buffer)."""
+
+    __slots__ = ("buf", "nbytes", "n", "first_record")
+
+    def __init__(self, buf: np.ndarray, nbytes: int, n: int, first_record: int):
+        self.buf, self.nbytes, self.n, self.first_record = buf, nbytes, n, first_record
+
+    def release(self) -> None:
+        if self.buf is not None:
+            fastq.PINNED.give(self.buf)
+            self.buf = None
+
+
+class TextReader(threading.Thread):
+    """One input file -> :class:`TextBlock` objects of exactly ``chunk_reads`` records (the last one may be shorter),
+    then ``None``.  Exceptions travel through the queue."""
+
+    def __init__(self, path: str, chunk_reads: int):
+        super().__init__(daemon=True, name=f"cutseq-read-{os.path.basename(path)}")
+        self.path, self.chunk_reads = path, chunk_reads
+        self.blocks: "queue.Queue" = queue.Queue(maxsize=3)
+        self._halt = False
+        self.gz = codec.is_gzip(path)
+        self.start()
+
+    # -- plumbing ---------------------------------------------------------------------------------------
+    def _put(self, item) -> bool:
+        while not self._halt:
+            try:
+                self.blocks.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def get(self) -> Optional[TextBlock]:
+        item = self.blocks.get()
+        if isinstance(item, fastq._Failure):
+            raise item.exc
+        return item
+
+    def close(self) -> None:
+        self._halt = True
+        deadline = time.monotonic() + 30.0
+        while self.is_alive() and time.monotonic() < deadline:
+            try:
+                while True:
+                    item = self.blocks.get_nowait()
+                    if isinstance(item, TextBlock):
+                        item.release()
+            except queue.Empty:
+                pass
+            self.join(timeout=0.05)
+
+    # -- sources: append text behind buf[:fill] -> (buf, fill, [(offset, nbytes, newlines)], eof) ------------------
+    @staticmethod
+    def _room(buf: np.ndarray, fill: int, want: int) -> np.ndarray:
+        if buf.size - fill >= want:
+            return buf
+        bigger = fastq.PINNED.take(max(buf.size + buf.size // 2, fill + want))
+        C.memmove(bigger.ctypes.data, buf.ctypes.data, fill)
+        fastq.PINNED.give(buf)
+        return bigger
+
+    def _read_plain(self, fd: int, pos: int, buf: np.ndarray, fill: int, want: int):
+        """``want`` bytes of the file from ``pos`` on, several preads (and newline counts) at once in the pool."""
+        L = _host()
+        pieces = max(1, min(8, (want + _BLOCK - 1) // _BLOCK))
+        want = pieces * _BLOCK
+        buf = self._room(buf, fill, want)
+        base = buf.ctypes.data
+        mv = memoryview(buf)
+
+        def job(i):
+            off = fill + i * _BLOCK
+            got = os.preadv(fd, [mv[off:off + _BLOCK]], pos + i * _BLOCK)
+            return got, (int(L.csh_count_newlines(base + off, got)) if got else 0)
+
+        pool = fastq._pool()
+        results = [f.result() for f in [pool.submit(job, i) for i in range(pieces)]] if pieces > 1 else [job(0)]
+        marks, eof, total = [], False, 0
+        for i, (got, lines) in enumerate(results):
+            if eof and got:  # a short piece in the middle: the file changed under us
+                raise OSError(f"{self.path}: short read")
+            if got:
+                marks.append((fill + i * _BLOCK, got, lines))
+                total += got
+            if got < _BLOCK:
+                eof = True
+        return buf, fill + total, marks, eof
+
+    def _run(self):
+        L = _host()
+        need = 4 * self.chunk_reads
+        est = 400  # bytes per record, corrected by every block that goes out
+        buf = fastq.PINNED.take(int(self.chunk_reads * est * 1.25) + 2 * _BLOCK)
+        fill, lines, done = 0, 0, 0
+        marks: List[tuple] = []  # (offset, nbytes, newlines) of every piece behind buf[:fill]
+        eof = False
+        fd, pos, gen = -1, 0, None
+        if self.gz:
+            src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give)
+            gen = src.blocks()
+        else:
+            fd = os.open(self.path, os.O_RDONLY)
+        try:
+            while not self._halt:
+                while lines < need and not eof:
+                    if gen is not None:
+                        item = next(gen, None)
+                        if item is None:
+                            eof = True
+                            break
+                        text, nbytes = item
+                        buf = self._room(buf, fill, nbytes)
+                        C.memmove(buf.ctypes.data + fill, text.ctypes.data, nbytes)
+                        if isinstance(text.base, fastq.mmap.mmap):
+                            fastq.ARENA.give(text)
+                        got = int(L.csh_count_newlines(buf.ctypes.data + fill, nbytes))
+                        marks.append((fill, nbytes, got))
+                        fill += nbytes
+                        lines += got
+                    else:
+                        missing = max(_BLOCK, int((need - lines) / 4 * est * 1.05) - 0)
+                        buf, fill, more, eof = self._read_plain(fd, pos, buf, fill, missing)
+                        pos += sum(m[1] for m in more)
+                        lines += sum(m[2] for m in more)
+                        marks += more
+                if lines >= need:
+                    # the block ends right behind newline number `need`: find the piece that holds it, then the byte
+                    cum, cut = 0, -1
+                    for off, nbytes, got in marks:
+                        if cum + got >= need:
+                            cut = off + int(L.csh_after_kth_newline(buf.ctypes.data + off, nbytes, need - cum))
+                            break
+                        cum += got
+                    assert cut > 0
+                    nxt = fastq.PINNED.take(max(buf.size, int(self.chunk_reads * est * 1.25) + 2 * _BLOCK))
+                    carry = fill - cut
+                    C.memmove(nxt.ctypes.data, buf.ctypes.data + cut, carry)
+                    block = TextBlock(buf, cut, self.chunk_reads, done)
+                    done += self.chunk_reads
+                    est = max(64, cut // self.chunk_reads + 1)
+                    buf, fill, lines = nxt, carry, lines - need
+                    marks = [(0, carry, lines)]
+                    if not self._put(block):
+                        block.release()
+                        return
+                    continue
+                # end of input: what is left must be whole records (blank lines behind the last one are tolerated)
+                end = fill
+                view = memoryview(buf)
+                while end > 0 and view[end - 1] in b"\n\r \t":
+                    end -= 1
+                if end == 0:
+                    fastq.PINNED.give(buf)
+                    buf = None
+                    self._put(None)
+                    return
+                tail_lines = int(L.csh_count_newlines(buf.ctypes.data, end)) + 1  # the last line lost its line end above
+                if tail_lines % 4:
+                    raise fastq.FastqFormatError(f"{self.path}: truncated FASTQ record at end of file")
+                block = TextBlock(buf, end, tail_lines // 4, done)
+                buf = None
+                if self._put(block):
+                    self._put(None)
+                else:
+                    block.release()
+                return
+        finally:
+            if buf is not None:
+                fastq.PINNED.give(buf)
+            if gen is not None:
+                gen.close()
+                src.close()
+            if fd >= 0:
+                os.close(fd)
+
+    def run(self):
+        try:
+            self._run()
+        except BaseException as exc:
+            self._put(fastq._Failure(exc))
+
+
+class _Shared:
+    """Output buffers of one batch on their way to several files: released when the last writer is done."""
+
+    def __init__(self, bufs, consumers: int, on_release):
+        self.bufs, self.left, self.on_release = bufs, consumers, on_release
+        self.lock = threading.Lock()
+        if consumers == 0:
+            self._release()
+
+    def _release(self):
+        for b in self.bufs:
+            fastq.PINNED.give(b)
+        self.bufs = ()
+        self.on_release()
+
+    def done(self):
+        with self.lock:
+            self.left -= 1
+            last = self.left == 0
+        if last:
+            self._release()
+
+
+class StreamWriter:
+    """One output file, written strictly in the order of :meth:`put`.  ``.gz``: the text goes out as gzip members
+    of about 4 MB, compressed in the pool (level 1 = cutadapt's default; any split of the text is a valid gzip
+    file and decompresses to the same bytes); plain: big pieces are written with several ``pwrite`` calls at once."""
+
+    def __init__(self, path: str, level: int = 1):
+        self.path, self.level, self.gz = path, level, path.endswith(".gz")
+        self.fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+        self.pos = 0
+        self.q: "queue.Queue" = queue.Queue()
+        self.err: Optional[BaseException] = None
+        self.t = threading.Thread(target=self._run, daemon=True, name=f"cutseq-write-{os.path.basename(path)}")
+        self.t.start()
+
+    def put(self, view: memoryview, shared: _Shared) -> None:
+        if self.err is not None:
+            shared.done()
+            raise self.err
+        if self.gz:
+            pool = fastq._pool()
+            futs = [pool.submit(codec.gzip_member, view[lo:lo + _GZ_PIECE], self.level) for lo in range(0, len(view), _GZ_PIECE)]
+            self.q.put((futs, shared))
+        else:
+            self.q.put((view, shared))
+
+    def _write_all(self, data) -> None:
+        mv = memoryview(data)
+        n = len(mv)
+        if n >= 2 * _PWRITE_PIECE:
+            pool = fastq._pool()
+
+            def piece(lo):
+                hi = min(n, lo + _PWRITE_PIECE)
+                at = lo
+                while at < hi:
+                    at += os.pwrite(self.fd, mv[at:hi], self.pos + at)
+
+            for f in [pool.submit(piece, lo) for lo in range(0, n, _PWRITE_PIECE)]:
+                f.result()
+        else:
+            at = 0
+            while at < n:
+                at += os.pwrite(self.fd, mv[at:], self.pos + at)
+        self.pos += n
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            payload, shared = item
+            try:
+                if self.err is None:
+                    if isinstance(payload, list):
+                        for f in payload:
+                            self._write_all(f.result())
+                    else:
+                        self._write_all(payload)
+                elif isinstance(payload, list):
+                    for f in payload:  # the views must not outlive their buffer
+                        try:
+                            f.result()
+                        except BaseException:
+                            pass
+            except BaseException as exc:
+                self.err = exc
+            finally:
+                shared.done()
+
+    def close(self) -> None:
+        self.q.put(None)
+        self.t.join()
+        try:
+            if self.err is None and self.gz and self.pos == 0:
+                self._write_all(codec.gzip_member(b"", self.level))  # an empty stream is still a valid gzip file
+        finally:
+            os.close(self.fd)
+        if self.err is not None:
+            raise self.err
+
+
+class _Done:
+    __slots__ = ("k", "n", "res", "out")
+
+    def __init__(self, k, n, res, out):
+        self.k, self.n, self.res, self.out = k, n, res, out
+
+
+class TextWorker(threading.Thread):
+    """One GPU.  Counterpart of one worker process of ``make_runner(inpaths, cores=N)`` (cutseq/run.py:436, 753)."""
+
+    SLOTS = 3
+
+    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int):
+        super().__init__(daemon=True, name=f"cutseq-gpu{device}")
+        self.tp, self.device, self.done, self.chunk_reads = tp, device, done, chunk_reads
+        self.inbox: "queue.Queue" = queue.Queue(maxsize=self.SLOTS)
+        self.engine = self.text = None
+        self.stride, self.capacity = 152, 0
+        self.stats = None
+        self.error: Optional[BaseException] = None
+        self.submitted = 0
+
+    def _collect_stats(self):
+        part = [s.as_dict() for s in self.engine.stats()]
+        self.stats = part if self.stats is None else [shard.merge_stats([a, b]) for a, b in zip(self.stats, part)]
+
+    def _ensure(self, inflight: deque, text_bytes: int, stride: Optional[int] = None):
+        """The text engine, rebuilt for longer rows or bigger blocks -- after everything in flight came back."""
+        stride = stride or self.stride
+        if self.text is not None and stride <= self.stride and text_bytes <= self.capacity:
+            return
+        from .engine import TrimEngine
+        while inflight:
+            self._finish(inflight)
+        if self.text is not None:
+            self.text.close()
+        if self.engine is None:
+            self.engine = TrimEngine(self.tp, device=self.device, slots=0)
+        self.stride = max(self.stride, stride)
+        self.capacity = max(self.capacity, int(text_bytes * 1.25) + (1 << 20))
+        self.text = textpath.TextEngine(self.engine, slots=self.SLOTS, max_text_bytes=self.capacity,
+                                        max_records=self.chunk_reads, stride=self.stride)
+        self.submitted = 0
+
+    def _submit(self, inflight: deque, k: int, b1: TextBlock, b2: Optional[TextBlock]):
+        slot = self.submitted % self.SLOTS
+        self.submitted += 1
+        self.text.submit(slot, b1.buf, b1.nbytes, b2.buf if b2 is not None else None, b2.nbytes if b2 is not None else 0, b1.n)
+        inflight.append((k, slot, b1, b2))
+
+    def _finish(self, inflight: deque):
+        k, slot, b1, b2 = inflight.popleft()
+        try:
+            res = self.text.wait(slot, first_record=b1.first_record)
+        except textpath.ReadLongerThanStride as exc:
+            # rows too short for this batch: everything else comes back first, then longer rows and once more
+            if exc.longest > abi.CS_MAX_STRIDE:
+                from .run import ReadTooLong
+                raise ReadTooLong(f"reads longer than {abi.CS_MAX_STRIDE} nt are not supported by the GPU tile "
+                                  f"(a read of {exc.longest} nt in records {b1.first_record + 1}..{b1.first_record + b1.n})")
+            self._ensure(inflight, max(b1.nbytes, b2.nbytes if b2 is not None else 0), stride=(exc.longest + 3) // 4 * 4)
+            self._submit(inflight, k, b1, b2)
+            return self._finish(inflight)
+        except textpath.TextFormatError as exc:
+            if exc.code == abi.CS_TEXT_ERR_IDS_DIFFER:
+                raise ValueError(str(exc))
+            raise fastq.FastqFormatError(str(exc))
+        out = [fastq.PINNED.take(max(int(res.out_bytes[m]), 1)) for m in range(2 if b2 is not None else 1)]
+        self.text.fetch(slot, out[0], out[1] if b2 is not None else None)
+        b1.release()
+        if b2 is not None:
+            b2.release()
+        self.done.put(_Done(k, b1.n, res, out))
+
+    def run(self):
+        inflight: deque = deque()
+        try:
+            while True:
+                item = self.inbox.get()
+                if item is None:
+                    break
+                k, b1, b2 = item
+                self._ensure(inflight, max(b1.nbytes, b2.nbytes if b2 is not None else 0))
+                if len(inflight) == self.SLOTS:
+                    self._finish(inflight)
+                self._submit(inflight, k, b1, b2)
+            while inflight:
+                self._finish(inflight)
+            if self.engine is not None:
+                self._collect_stats()
+        except BaseException as exc:
+            self.error = exc
+        finally:
+            try:
+                if self.text is not None:
+                    self.text.close()
+                if self.engine is not None:
+                    self.engine.close()
+            finally:
+                self.done.put(self)
+
+
+def run_text_pipeline(args, tp, devices, chunk_reads: int) -> dict:
+    """The CLI's run on the text path -> the run statistics ``report`` expects."""
+    paired = tp.paired
+    in1 = args.input_file[0]
+    in2 = args.input_file[1] if paired else None
+    r1 = TextReader(in1, chunk_reads)  # (a missing input file raises here, before anything else exists)
+    r2 = None
+    opened: List[StreamWriter] = []
+    try:
+        r2 = TextReader(in2, chunk_reads) if paired else None
+
+        def mk(names):
+            group = []
+            for n in names:
+                group.append(StreamWriter(n) if n else None)
+                if group[-1] is not None:
+                    opened.append(group[-1])
+            return group
+
+        trimmed = mk(args.output_file)
+        if paired and tp.swap_outputs:
+            trimmed = trimmed[::-1]
+        outs = [trimmed, mk(args.short_file), mk(args.untrimmed_file)]
+    except BaseException:
+        r1.close()
+        if r2 is not None:
+            r2.close()
+        for fh in opened:
+            try:
+                fh.close()
+            except BaseException:
+                pass
+        raise
+    totals = report.new_totals()
+    t0 = time.perf_counter()
+    done: "queue.Queue" = queue.Queue()
+    workers = [TextWorker(tp, dev, done, chunk_reads) for dev in devices]
+    budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk
+    failure: List[BaseException] = []
+
+    def emit(item: _Done):
+        res = item.res
+        totals["in_pairs"] += item.n
+        for q in range(3):
+            totals["routes"][q] += int(res.route_count[q])
+        for m in range(2 if paired else 1):
+            totals["written_bp"][m] += int(res.written_bp[m])
+        jobs = []
+        for m in range(2 if paired else 1):
+            at = 0
+            for route in range(3):
+                nbytes = int(res.route_bytes[route][m])
+                fh = (outs[route] + [None])[m]
+                if nbytes and fh is not None:
+                    jobs.append((fh, memoryview(item.out[m])[at:at + nbytes]))
+                at += nbytes
+        shared = _Shared(item.out, len(jobs), budget.release)
+        for fh, view in jobs:
+            fh.put(view, shared)
+
+    def collect():
+        waiting, next_k, alive = {}, 0, len(workers)
+        try:
+            while alive or waiting:
+                item = done.get()
+                if isinstance(item, TextWorker):
+                    alive -= 1
+                    if item.error is not None:
+                        raise item.error
+                    if not alive and waiting and next_k not in waiting:
+                        raise RuntimeError("a batch went missing between the GPU workers and the writers")
+                    continue
+                waiting[item.k] = item
+                while next_k in waiting:
+                    emit(waiting.pop(next_k))
+                    next_k += 1
+        except BaseException as exc:
+            failure.append(exc)
+            while alive:  # keep the workers from blocking on a dead consumer
+                item = done.get()
+                if isinstance(item, TextWorker):
+                    alive -= 1
+                else:
+                    for b in item.out:
+                        fastq.PINNED.give(b)
+                    budget.release()
+
+    collector = threading.Thread(target=collect, daemon=True, name="cutseq-collect")
+    for w in workers:
+        w.start()
+    collector.start()
+    first_error: Optional[BaseException] = None
+    try:
+        k = 0
+        while not failure:
+            b1 = r1.get()
+            b2 = r2.get() if r2 is not None else None
+            if b1 is None and b2 is None:
+                break
+            if r2 is not None and (b1 is None or b2 is None or b1.n != b2.n):
+                for b in (b1, b2):
+                    if b is not None:
+                        b.release()
+                raise fastq.FastqFormatError(
+                    "Reads are improperly paired! There are more reads in one file than in the other, "
+                    "or a record is truncated.")
+            while not budget.acquire(timeout=0.2):
+                if failure:
+                    break
+            w = workers[k % len(workers)]
+            while not failure:
+                try:
+                    w.inbox.put((k, b1, b2), timeout=0.2)
+                    break
+                except queue.Full:
+                    continue
+            k += 1
+    except BaseException as exc:
+        first_error = exc
+    finally:
+        r1.close()
+        if r2 is not None:
+            r2.close()
+        for w in workers:
+            while True:
+                try:
+                    w.inbox.put(None, timeout=0.2)
+                    break
+                except queue.Full:
+                    if not w.is_alive():
+                        break
+        for w in workers:
+            w.join()
+        collector.join()
+        for group in outs:
+            for fh in group:
+                if fh is None:
+                    continue
+                try:
+                    fh.close()
+                except BaseException as exc:
+                    first_error = first_error or exc
+    if first_error is None and failure:
+        first_error = failure[0]
+    if first_error is None:
+        first_error = next((w.error for w in workers if w.error is not None), None)
+    if first_error is not None:
+        raise first_error
+    # (the pinned arena stays: page-locking gigabytes costs more than a short run; it is freed when the process ends)
+    stats = [w.stats for w in workers if w.stats is not None]
+    for m in range(2 if paired else 1):
+        totals["in_bp"][m] = sum(int(pair[m]["in_bp"]) for pair in stats)
+        totals["out_bp"][m] = sum(int(pair[m]["out_bp"]) for pair in stats)
+    totals["seconds"] = time.perf_counter() - t0
+    totals["bin_names"] = None
+    totals["stats"] = stats
+    totals["devices"] = devices
+    totals["path"] = "text"
+    return totals

@@ -290,6 +290,7 @@ typedef struct cs_text_result {
   uint32_t _pad;
   uint64_t route_bytes[3][2]; /* [route][mate]                                                                  */
   uint64_t out_bytes[2];      /* per mate: sum over the routes = what cs_text_fetch copies                      */
+  uint64_t written_bp[2];     /* per mate: bases of the records of route 0 (cutadapt's written_bp)              */
 } cs_text_result;
 
 typedef struct cs_text cs_text;

@@ -554,3 +554,81 @@ def test_replayed_counters_need_matching_kernel_sources(tmp_path):
     got, why = bench.replayed_counters(str(f), 2000)
     assert got is None and "pairs per launch" in why
     assert bench.replayed_counters(str(tmp_path / "nope.json"), 1)[0] is None
+
+
+# ---------------------------------------------------------------- text path, host side (reader / writer; no GPU)
+
+
+@pytest.fixture
+def unpinned(monkeypatch):
+    """The text path keeps its blocks in page-locked memory; without a GPU an ordinary arena stands in."""
+    monkeypatch.setattr(fastq, "PINNED", fastq._Arena())
+
+
+def _drain(reader):
+    got, sizes = b"", []
+    while True:
+        b = reader.get()
+        if b is None:
+            break
+        got += bytes(memoryview(b.buf)[: b.nbytes])
+        sizes.append(b.n)
+        b.release()
+    reader.close()
+    return got, sizes
+
+
+@pytest.mark.parametrize("container", ["plain", "plain-no-final-newline", "crlf+blank-tail", "gz-members", "gz-one-member"])
+def test_text_reader_cuts_blocks_of_whole_records(tmp_path, unpinned, container):
+    """textio.TextReader: exactly chunk_reads records per block (the last one shorter), bytes untouched, for every
+    container the CLI reads (reference: dnaio through runner.run, cutseq/run.py:434-441)."""
+    from cutseq_amd import textio
+    recs = [b"@r%d x\n%s\n+\n%s\n" % (i, b"ACGT" * (5 + i % 40), b"IIII" * (5 + i % 40)) for i in range(25_001)]
+    body = b"".join(recs)
+    path = tmp_path / ("in.fq.gz" if container.startswith("gz") else "in.fq")
+    data = body
+    if container == "plain-no-final-newline":
+        data = body[:-1]
+    elif container == "crlf+blank-tail":
+        data = body.replace(b"\n", b"\r\n") + b"\r\n\n"
+    if container == "gz-members":
+        with open(path, "wb") as fh:
+            for lo in range(0, len(recs), 3000):
+                fh.write(gzip.compress(b"".join(recs[lo:lo + 3000]), 1))
+    elif container == "gz-one-member":
+        path.write_bytes(gzip.compress(body, 1))
+    else:
+        path.write_bytes(data)
+    got, sizes = _drain(textio.TextReader(str(path), 7000))
+    assert sizes == [7000, 7000, 7000, 4001]
+    assert got == data.rstrip(b"\r\n")  # (only the line end of the very last record may go)
+    # one record too few lines: the reader says so instead of handing a ragged block on
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(body + b"@x\nACGT\n")
+    with pytest.raises(fastq.FastqFormatError):
+        _drain(textio.TextReader(str(bad), 7000))
+    empty = tmp_path / "empty.fq"
+    empty.write_bytes(b"")
+    assert _drain(textio.TextReader(str(empty), 7000)) == (b"", [])
+
+
+def test_stream_writer_orders_pieces_and_releases_buffers(tmp_path, unpinned):
+    from cutseq_amd import textio
+    rng = np.random.default_rng(1)
+    parts = [rng.integers(65, 90, size=n, dtype=np.uint8) for n in (10, 5_000_000, 0, 17_000_000, 123)]
+    for name in ("o.fq", "o.fq.gz"):
+        released = []
+        w = textio.StreamWriter(str(tmp_path / name))
+        for i, p in enumerate(parts):
+            if p.size:
+                buf = fastq.PINNED.take(p.size)
+                buf[: p.size] = p
+                w.put(memoryview(buf)[: p.size], textio._Shared([buf], 1, lambda i=i: released.append(i)))
+        w.close()
+        want = b"".join(p.tobytes() for p in parts)
+        raw = (tmp_path / name).read_bytes()
+        assert (gzip.decompress(raw) if name.endswith(".gz") else raw) == want
+        assert sorted(released) == [0, 1, 3, 4]
+    w = textio.StreamWriter(str(tmp_path / "none.fq.gz"))
+    w.close()
+    assert gzip.decompress((tmp_path / "none.fq.gz").read_bytes()) == b""
