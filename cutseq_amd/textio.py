@@ -33,6 +33,21 @@ _GZ_PIECE = 4 << 20       # output text per gzip member
 _PWRITE_PIECE = 8 << 20
 
 
+PROFILE = os.environ.get("CUTSEQ_PROFILE") == "1"
+_prof = {}
+_prof_lock = threading.Lock()
+
+
+def _tick(key: str, t0: float) -> float:
+    """Diagnostic (CUTSEQ_PROFILE=1): seconds per thread and activity, printed at the end of the run."""
+    now = time.perf_counter()
+    if PROFILE:
+        name = f"{threading.current_thread().name}:{key}"
+        with _prof_lock:
+            _prof[name] = _prof.get(name, 0.0) + (now - t0)
+    return now
+
+
 def _host():
     L = fastq._lib()
     if not getattr(L, "_text_bound", False):
@@ -72,13 +87,17 @@ class TextReader(threading.Thread):
 
     # -- plumbing ---------------------------------------------------------------------------------------
     def _put(self, item) -> bool:
-        while not self._halt:
-            try:
-                self.blocks.put(item, timeout=0.2)
-                return True
-            except queue.Full:
-                continue
-        return False
+        t0 = time.perf_counter()
+        try:
+            while not self._halt:
+                try:
+                    self.blocks.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+        finally:
+            _tick("blocked_on_consumer", t0)
 
     def get(self) -> Optional[TextBlock]:
         item = self.blocks.get()
@@ -169,12 +188,15 @@ class TextReader(threading.Thread):
                         lines += got
                     else:
                         missing = max(_BLOCK, int((need - lines) / 4 * est * 1.05) - 0)
+                        t0 = time.perf_counter()
                         buf, fill, more, eof = self._read_plain(fd, pos, buf, fill, missing)
+                        _tick("read", t0)
                         pos += sum(m[1] for m in more)
                         lines += sum(m[2] for m in more)
                         marks += more
                 if lines >= need:
                     # the block ends right behind newline number `need`: find the piece that holds it, then the byte
+                    t0 = time.perf_counter()
                     cum, cut = 0, -1
                     for off, nbytes, got in marks:
                         if cum + got >= need:
@@ -190,6 +212,7 @@ class TextReader(threading.Thread):
                     est = max(64, cut // self.chunk_reads + 1)
                     buf, fill, lines = nxt, carry, lines - need
                     marks = [(0, carry, lines)]
+                    _tick("cut+carry", t0)
                     if not self._put(block):
                         block.release()
                         return
@@ -300,7 +323,9 @@ class StreamWriter:
 
     def _run(self):
         while True:
+            t0 = time.perf_counter()
             item = self.q.get()
+            t0 = _tick("idle", t0)
             if item is None:
                 return
             payload, shared = item
@@ -308,9 +333,13 @@ class StreamWriter:
                 if self.err is None:
                     if isinstance(payload, list):
                         for f in payload:
-                            self._write_all(f.result())
+                            blob = f.result()
+                            t0 = _tick("wait_deflate", t0)
+                            self._write_all(blob)
+                            t0 = _tick("write", t0)
                     else:
                         self._write_all(payload)
+                        _tick("write", t0)
                 elif isinstance(payload, list):
                     for f in payload:  # the views must not outlive their buffer
                         try:
@@ -386,8 +415,10 @@ class TextWorker(threading.Thread):
 
     def _finish(self, inflight: deque):
         k, slot, b1, b2 = inflight.popleft()
+        t0 = time.perf_counter()
         try:
             res = self.text.wait(slot, first_record=b1.first_record)
+            t0 = _tick("wait", t0)
         except textpath.ReadLongerThanStride as exc:
             # rows too short for this batch: everything else comes back first, then longer rows and once more
             if exc.longest > abi.CS_MAX_STRIDE:
@@ -402,7 +433,9 @@ class TextWorker(threading.Thread):
                 raise ValueError(str(exc))
             raise fastq.FastqFormatError(str(exc))
         out = [fastq.PINNED.take(max(int(res.out_bytes[m]), 1)) for m in range(2 if b2 is not None else 1)]
+        t0 = _tick("take", t0)
         self.text.fetch(slot, out[0], out[1] if b2 is not None else None)
+        _tick("fetch", t0)
         b1.release()
         if b2 is not None:
             b2.release()
@@ -412,14 +445,19 @@ class TextWorker(threading.Thread):
         inflight: deque = deque()
         try:
             while True:
+                t0 = time.perf_counter()
                 item = self.inbox.get()
+                t0 = _tick("idle", t0)
                 if item is None:
                     break
                 k, b1, b2 = item
                 self._ensure(inflight, max(b1.nbytes, b2.nbytes if b2 is not None else 0))
+                t0 = _tick("ensure", t0)
                 if len(inflight) == self.SLOTS:
                     self._finish(inflight)
+                t0 = time.perf_counter()
                 self._submit(inflight, k, b1, b2)
+                _tick("submit", t0)
             while inflight:
                 self._finish(inflight)
             if self.engine is not None:
@@ -531,8 +569,10 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int) -> dict:
     try:
         k = 0
         while not failure:
+            t0 = time.perf_counter()
             b1 = r1.get()
             b2 = r2.get() if r2 is not None else None
+            _tick("main_wait_readers", t0)
             if b1 is None and b2 is None:
                 break
             if r2 is not None and (b1 is None or b2 is None or b1.n != b2.n):
@@ -594,4 +634,11 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int) -> dict:
     totals["stats"] = stats
     totals["devices"] = devices
     totals["path"] = "text"
+    if PROFILE:
+        import json
+        import sys
+        with _prof_lock:
+            print(json.dumps({"cutseq_profile": {k: round(v, 3) for k, v in sorted(_prof.items())},
+                              "seconds": round(totals["seconds"], 3)}), file=sys.stderr)
+            _prof.clear()
     return totals

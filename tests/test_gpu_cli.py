@@ -116,6 +116,7 @@ def test_cli_many_chunks_two_engines_on_one_gpu(tmp_path, monkeypatch):
     util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1, gz_members=30_000)
     util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=50_000)
     monkeypatch.setenv("CUTSEQ_DEVICES", "0,0")
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "65536")  # (the text path's default block is 262 144 records)
     prefix = str(tmp_path / "out")
     cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", prefix, "--json-file", str(tmp_path / "r.json"), in1, in2])
     got = read_streams(prefix, True)
