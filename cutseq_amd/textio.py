@@ -16,6 +16,7 @@ order.  Counterpart of ``runner.run(pipeline, Progress(), outfiles)`` with ``mak
 from __future__ import annotations
 
 import ctypes as C
+import mmap
 import os
 import queue
 import threading
@@ -30,7 +31,9 @@ from . import abi, codec, fastq, report, shard, textpath
 CHUNK_READS = 1 << 18
 _BLOCK = 8 << 20          # bytes per pread / per inflate hand-over
 _GZ_PIECE = 4 << 20       # output text per gzip member
-_PWRITE_PIECE = 8 << 20
+_COPY_PIECE = 4 << 20     # plain output: bytes per parallel copy into the file mapping
+_MAP_MIN = 8 << 20        # ... used from this size on (smaller pieces go through pwrite)
+_PAGE = mmap.ALLOCATIONGRANULARITY
 
 
 PROFILE = os.environ.get("CUTSEQ_PROFILE") == "1"
@@ -283,8 +286,9 @@ class StreamWriter:
 
     def __init__(self, path: str, level: int = 1):
         self.path, self.level, self.gz = path, level, path.endswith(".gz")
-        self.fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+        self.fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
         self.pos = 0
+        self.mappable = not self.gz
         self.q: "queue.Queue" = queue.Queue()
         self.err: Optional[BaseException] = None
         self.t = threading.Thread(target=self._run, daemon=True, name=f"cutseq-write-{os.path.basename(path)}")
@@ -302,24 +306,43 @@ class StreamWriter:
             self.q.put((view, shared))
 
     def _write_all(self, data) -> None:
+        """``data`` at the end of the file.  Writes to ONE file serialise on its inode lock whatever the number of
+        threads, so big plain pieces do not go through write(2): the file is extended, the new range mapped, and the
+        pool copies into the mapping -- page faults and copies of different pages run side by side."""
         mv = memoryview(data)
         n = len(mv)
-        if n >= 2 * _PWRITE_PIECE:
-            pool = fastq._pool()
-
-            def piece(lo):
-                hi = min(n, lo + _PWRITE_PIECE)
-                at = lo
-                while at < hi:
-                    at += os.pwrite(self.fd, mv[at:hi], self.pos + at)
-
-            for f in [pool.submit(piece, lo) for lo in range(0, n, _PWRITE_PIECE)]:
-                f.result()
-        else:
-            at = 0
-            while at < n:
-                at += os.pwrite(self.fd, mv[at:], self.pos + at)
+        if n >= _MAP_MIN and self.mappable:
+            try:
+                self._copy_mapped(mv, n)
+                self.pos += n
+                return
+            except (OSError, ValueError, BufferError):
+                self.mappable = False  # a file system without usable shared mappings: plain writes from here on
+                os.ftruncate(self.fd, self.pos)
+        at = 0
+        while at < n:
+            at += os.pwrite(self.fd, mv[at:], self.pos + at)
         self.pos += n
+
+    def _copy_mapped(self, mv: memoryview, n: int) -> None:
+        start, end = self.pos, self.pos + n
+        os.ftruncate(self.fd, end)
+        base = start - start % _PAGE
+        mm = mmap.mmap(self.fd, end - base, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE, offset=base)
+        try:
+            dst = np.frombuffer(mm, dtype=np.uint8)
+            src = np.frombuffer(mv, dtype=np.uint8)
+            d0, s0 = dst.ctypes.data + (start - base), src.ctypes.data
+            pool = fastq._pool()
+            futs = [pool.submit(C.memmove, d0 + lo, s0 + lo, min(_COPY_PIECE, n - lo)) for lo in range(0, n, _COPY_PIECE)]
+            for f in futs:
+                f.result()
+            del dst, src
+        finally:
+            try:
+                mm.close()
+            except BufferError:  # (an exception above left a view alive: the mapping goes with the garbage collector)
+                pass
 
     def _run(self):
         while True:
@@ -508,7 +531,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int) -> dict:
                 pass
         raise
     totals = report.new_totals()
-    t0 = time.perf_counter()
+    t_start = time.perf_counter()
     done: "queue.Queue" = queue.Queue()
     workers = [TextWorker(tp, dev, done, chunk_reads) for dev in devices]
     budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk
@@ -629,7 +652,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int) -> dict:
     for m in range(2 if paired else 1):
         totals["in_bp"][m] = sum(int(pair[m]["in_bp"]) for pair in stats)
         totals["out_bp"][m] = sum(int(pair[m]["out_bp"]) for pair in stats)
-    totals["seconds"] = time.perf_counter() - t0
+    totals["seconds"] = time.perf_counter() - t_start
     totals["bin_names"] = None
     totals["stats"] = stats
     totals["devices"] = devices

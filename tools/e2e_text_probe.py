@@ -51,10 +51,12 @@ def main():
 
     run("plain warm-up", plain_in, plain_out)
     run("plain", plain_in, plain_out)
-    run("plain 2 engines", plain_in, plain_out, CUTSEQ_DEVICES="0,0")
-    run("plain blocks of 131072", plain_in, plain_out, CUTSEQ_CHUNK_READS=131072)
-    run("plain blocks of 524288", plain_in, plain_out, CUTSEQ_CHUNK_READS=524288)
-    run("plain host path", plain_in, plain_out, CUTSEQ_TEXT_PATH=0)
+    run("plain again", plain_in, plain_out)
+    if "--more" in sys.argv:
+        run("plain 2 engines", plain_in, plain_out, CUTSEQ_DEVICES="0,0")
+        run("plain blocks of 131072", plain_in, plain_out, CUTSEQ_CHUNK_READS=131072)
+        run("plain blocks of 524288", plain_in, plain_out, CUTSEQ_CHUNK_READS=524288)
+        run("plain host path", plain_in, plain_out, CUTSEQ_TEXT_PATH=0)
     run("gz->gz", gz_in, ["-O", str(work / "gzout")])
     run("gz->gz 2 engines", gz_in, ["-O", str(work / "gzout")], CUTSEQ_DEVICES="0,0")
     run("gz->plain", gz_in, plain_out)
