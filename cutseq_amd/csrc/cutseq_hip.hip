@@ -12,6 +12,7 @@
 
 #include "../../include/cutseq_hip.h"
 #include "trim_kernel.hip.inc"
+#include "finish_kernel.hip.inc"
 #include "text_kernels.hip.inc"
 
 namespace {
@@ -58,6 +59,7 @@ struct Slot {
 struct Lane {
   uint32_t *d_counters = nullptr;
   void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
+  void *d_carry[2] = {nullptr, nullptr};  // per mate: carry records of the split form (16 bytes per read)
   uint32_t defer_capacity = 0;            // records per mate
   hipEvent_t scanned = nullptr;           // scan kernel finished (what the resolve stream waits for)
   hipEvent_t done = nullptr;              // resolve kernel finished
@@ -115,6 +117,9 @@ struct cs_engine {
   uint32_t n_table_ops = 1;
   uint32_t col_dwords = 0;   // per-wave DP scratch the plan needs (resolve kernel)
   uint32_t waves_per_simd[2] = {4, 4};  // scan / resolve kernel, from their register counts
+  // split form: the scan kernel stops behind the leading Myers adapter ops, the finish kernel walks the rest
+  bool lean = false;
+  uint32_t lean_ops[2] = {0, 0};
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds[2] = {0, 0};
   std::vector<void *> d_tables;           // device copies of the CS_OP_DEMUX tables
@@ -217,7 +222,8 @@ const void *kernel_of(const cs_engine *eng) {
                    : reinterpret_cast<const void *>(csdev::trim_kernel<false, false, MODE>);
 }
 const void *kernel_for(const cs_engine *eng, int mode) {
-  return mode == csdev::MODE_SCAN ? kernel_of<csdev::MODE_SCAN>(eng) : kernel_of<csdev::MODE_RESOLVE>(eng);
+  if (mode == csdev::MODE_RESOLVE) return kernel_of<csdev::MODE_RESOLVE>(eng);
+  return eng->lean ? kernel_of<csdev::MODE_LEAN>(eng) : kernel_of<csdev::MODE_SCAN>(eng);
 }
 
 int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
@@ -230,7 +236,9 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   // resolve kernel runs the DP: scratch columns and the survivor queue are its alone.
   g.tile_rows = kTileRows;
   g.col_dwords = 0;
-  uint32_t words = kTileRows * g.lds_stride_dw + eng->n_table_ops * (csdev::kEqTableBytes / 4 + csdev::kFnibDwords) +
+  uint32_t table_ops = eng->n_table_ops;
+  if (mode == csdev::MODE_SCAN && eng->lean) table_ops = eng->lean_ops[0] > eng->lean_ops[1] ? eng->lean_ops[0] : eng->lean_ops[1];
+  uint32_t words = kTileRows * g.lds_stride_dw + table_ops * (csdev::kEqTableBytes / 4 + csdev::kFnibDwords) +
                    csdev::kStatWords +
                    96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
   if (mode == csdev::MODE_SCAN) words += csdev::kRingRecords * 8;  // queue records waiting for their reservation
@@ -300,10 +308,14 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
       if (l.used) HIP_TRY(hipEventSynchronize(l.done));  // an earlier launch may still be reading the old queue
       for (int m = 0; m < 2; ++m) {
         if (l.d_defer[m]) (void)hipFree(l.d_defer[m]);
-        l.d_defer[m] = nullptr;
+        if (l.d_carry[m]) (void)hipFree(l.d_carry[m]);
+        l.d_defer[m] = l.d_carry[m] = nullptr;
       }
       l.defer_capacity = 0;
-      for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) HIP_TRY(hipMalloc(&l.d_defer[m], (size_t)cap * kDeferRecordBytes));
+      for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) {
+        HIP_TRY(hipMalloc(&l.d_defer[m], (size_t)cap * kDeferRecordBytes));
+        if (eng->lean) HIP_TRY(hipMalloc(&l.d_carry[m], (size_t)cap * sizeof(uint4)));
+      }
       l.defer_capacity = cap;
     }
   }
@@ -318,6 +330,10 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   a.n_table_ops = eng->n_table_ops;
   a.batch_knob = eng->knob_batch;
   a.gate = gate;
+  for (int m = 0; m < 2; ++m) {
+    a.carry[m] = reinterpret_cast<uint4 *>(ln.d_carry[m]);
+    a.lean_ops[m] = eng->lean_ops[m];
+  }
   for (int mode = 0; mode < 2; ++mode)
     if (g[mode].lds_bytes > eng->max_dynamic_lds[mode]) {
       HIP_TRY(hipFuncSetAttribute(kernel_for(eng, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g[mode].lds_bytes));
@@ -364,12 +380,41 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   for (int mode = 0; mode < 2; ++mode) {
     a.lds_stride_dw = g[mode].lds_stride_dw;
     a.col_dwords = g[mode].col_dwords;
+    a.n_table_ops = eng->n_table_ops;
+    if (mode == csdev::MODE_SCAN && eng->lean) a.n_table_ops = eng->lean_ops[0] > eng->lean_ops[1] ? eng->lean_ops[0] : eng->lean_ops[1];
     void *kargs[] = {&a};
     hipStream_t st = mode == csdev::MODE_SCAN ? stream : rstream;
     if (mode == csdev::MODE_RESOLVE && rstream != stream) {
       // (one marker on the scan stream serves the timing and the hand-over: ev_mid when the call is timed)
       if (!time_it) HIP_TRY(hipEventRecord(ln.scanned, stream));
       HIP_TRY(hipStreamWaitEvent(rstream, time_it ? ln.ev_mid : ln.scanned, 0));
+    }
+    if (mode == csdev::MODE_RESOLVE && eng->lean) {
+      // split form: the rest of the chain for every read the scan kernel carried over, in front of the resolve kernel
+      // (it may add reads of its own to the queue)
+      csdev::FinishArgs fa;
+      memset(&fa, 0, sizeof fa);
+      for (uint32_t m = 0; m < mates; ++m) {
+        fa.mate[m] = a.mate[m];
+        fa.carry[m] = a.carry[m];
+        fa.first_op[m] = eng->lean_ops[m];
+        fa.defer[m] = a.defer[m];
+      }
+      fa.stats = a.stats;
+      fa.n_reads = n_reads;
+      fa.stride_dw = a.stride_dw;
+      fa.plan_slot = a.plan_slot;
+      fa.defer_count = a.defer_count;
+      fa.gate = gate;
+      uint32_t fgx = (n_tiles + 3u) / 4u;
+      const uint32_t fcap = (uint32_t)eng->n_cus * 8u / mates;
+      if (fgx > fcap) fgx = fcap;
+      if (fgx < 1) fgx = 1;
+      void *fargs[] = {&fa};
+      const void *fk = eng->coded ? reinterpret_cast<const void *>(csdev::finish_kernel<true>)
+                                  : reinterpret_cast<const void *>(csdev::finish_kernel<false>);
+      HIP_TRY(hipLaunchKernel(fk, dim3(fgx, mates, 1), dim3(256, 1, 1), fargs, 0, st));
+      HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
                             g[mode].lds_bytes, st));
@@ -502,8 +547,10 @@ void cs_engine_destroy(cs_engine *eng) {
   for (Lane &ln : eng->lanes) {
     if (ln.used) (void)hipEventSynchronize(ln.done);
     if (ln.d_counters) (void)hipFree(ln.d_counters);
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
       if (ln.d_defer[m]) (void)hipFree(ln.d_defer[m]);
+      if (ln.d_carry[m]) (void)hipFree(ln.d_carry[m]);
+    }
     for (hipEvent_t ev : {ln.scanned, ln.done, ln.ev_start, ln.ev_mid, ln.ev_stop})
       if (ev) (void)hipEventDestroy(ev);
   }
@@ -552,6 +599,28 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
       const uint32_t need = (d.acgt_only && d.op.m <= 32) ? 16u * (d.op.m + 1u) : 2u * (d.op.m + 1u);
       if (need > eng->col_dwords) eng->col_dwords = need;
     }
+  // Split form: possible when the chain is [Myers adapter ops] [cuts / demultiplexing /
+  // homopolymer ops / quality trimming], which every chain cutseq/run.py compiles is.  CUTSEQ_LEAN=0/1 overrides.
+  {
+    bool ok = plan->host.params.use_filter != 0;
+    for (int mt = 0; mt < 2 && ok; ++mt) {
+      const int n = plan->host.n_ops[mt];
+      int lead = 0;
+      while (lead < n && plan->host.ops[mt][lead].op.kind == CS_OP_ADAPTER &&
+             (plan->host.ops[mt][lead].filter_mode == csdev::FILTER_MYERS32 ||
+              plan->host.ops[mt][lead].filter_mode == csdev::FILTER_MYERS64))
+        ++lead;
+      eng->lean_ops[mt] = (uint32_t)lead;
+      for (int i = lead; i < n && ok; ++i) {
+        const csdev::DevOp &d = plan->host.ops[mt][i];
+        if (d.op.kind == CS_OP_ADAPTER)
+          ok = (d.filter_mode == csdev::FILTER_POLY_TAIL || d.filter_mode == csdev::FILTER_POLY_HEAD) && d.op.m <= 128;
+      }
+      if (n > 0 && (lead == 0 || lead == n)) ok = false;  // nothing to split off / nothing left behind the scans
+    }
+    const char *env = getenv("CUTSEQ_LEAN");
+    eng->lean = ok && !(env && atoi(env) == 0);
+  }
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
 #define ENG_TRY(expr)                                                                     \

@@ -44,6 +44,9 @@ def main():
     out["gunzip_s"] = round(time.perf_counter() - t0, 2)
 
     def run(tag, inputs, outputs):
+        for old in work.glob("o[12].fastq"), work.glob("s[12].fastq"), work.glob("gzout_*"):
+            for f in old:  # a run writes NEW files: freeing the previous run's gigabytes of tmpfs pages is not its job
+                f.unlink()
         t0 = time.perf_counter()
         try:
             cli.main(["-A", "TAKARAV3", "--trim-polyA"] + inputs + outputs)
