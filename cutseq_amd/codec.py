@@ -169,21 +169,32 @@ class GzipSource:
                 pass
         self.fh.close()
 
-    def blocks(self) -> Iterator[tuple]:
+    def blocks(self, start: int = 0) -> Iterator[tuple]:
+        """(buffer, nbytes) pairs from the member that begins at compressed offset ``start`` on."""
+        for _, arr, nbytes in self.indexed_blocks(start):
+            yield arr, nbytes
+
+    def indexed_blocks(self, start: int = 0) -> Iterator[tuple]:
+        """(compressed offset at which the block's first member starts, buffer, nbytes); the offset is -1 when the
+        stream cannot be entered anywhere but at its start (one huge member, no libdeflate).  What the multi-process
+        form of the CLI (``ranks.py``) builds its split points from."""
         if self.map is None:
             return
         if libdeflate() is None:
-            yield from self._zlib_stream(0)
+            if start:
+                raise OSError(f"{self.path}: cannot start inside a gzip stream without libdeflate")
+            for arr, nbytes in self._zlib_stream(0):
+                yield -1, arr, nbytes
             return
-        if _bgzf_block_size(self.map, 0):
-            yield from self._bgzf()
+        if _bgzf_block_size(self.map, start):
+            yield from self._bgzf(start)
             return
-        yield from self._members()
+        yield from self._members(start)
 
     # -- BGZF: boundaries are in the headers, spans of blocks inflate in parallel ------------------
-    def _bgzf(self) -> Iterator[bytes]:
+    def _bgzf(self, start: int = 0) -> Iterator[tuple]:
         buf, n = self.map, self.size
-        spans, lo, pos = [], 0, 0
+        spans, lo, pos = [], start, start
         while pos < n:
             size = _bgzf_block_size(buf, pos)
             if size == 0:  # a foreign member in the middle: the rest goes member by member
@@ -197,16 +208,18 @@ class GzipSource:
         tail = pos
         if self.pool is None:
             for a, b in spans:
-                yield _inflate_span(buf, a, b, 4 * (b - a), self.take, self.give)
+                yield (a,) + _inflate_span(buf, a, b, 4 * (b - a), self.take, self.give)
         else:
             from collections import deque
             pending = deque()
             for a, b in spans:
-                pending.append(self.pool.submit(_inflate_span, buf, a, b, 4 * (b - a), self.take, self.give))
+                pending.append((a, self.pool.submit(_inflate_span, buf, a, b, 4 * (b - a), self.take, self.give)))
                 if len(pending) >= 8:
-                    yield pending.popleft().result()
+                    a0, fut = pending.popleft()
+                    yield (a0,) + fut.result()
             while pending:
-                yield pending.popleft().result()
+                a0, fut = pending.popleft()
+                yield (a0,) + fut.result()
         if tail < n:
             yield from self._members(tail)
 
@@ -282,12 +295,13 @@ class GzipSource:
                 if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
                     for p in list(tasks):
                         drop(p)
-                    yield from self._zlib_stream(head)
+                    for arr, nbytes in self._zlib_stream(head):
+                        yield -1, arr, nbytes
                     return
                 if rc != 0:
                     raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
                 cap[0] = max(cap[0], min(_MEMBER_CAP, 1 << max(produced - 1, 1).bit_length()))
-                yield out, produced
+                yield head, out, produced
                 head += used
                 while cands and cands[0] <= head:
                     p = cands.pop(0)
@@ -325,13 +339,15 @@ class GzipSource:
                 break
             if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
                 self.give(out)
-                yield from self._zlib_stream(pos)
+                for arr, nbytes in self._zlib_stream(pos):
+                    yield -1, arr, nbytes
                 return
             if rc != 0:
                 self.give(out)
                 raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
+            at = pos
             pos += n_in.value
-            yield out, int(n_out.value)
+            yield at, out, int(n_out.value)
 
     # -- fallback: zlib streaming, any member size -------------------------------------------------
     def _zlib_stream(self, start: int) -> Iterator[tuple]:

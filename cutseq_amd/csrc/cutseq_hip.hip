@@ -599,8 +599,10 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
       const uint32_t need = (d.acgt_only && d.op.m <= 32) ? 16u * (d.op.m + 1u) : 2u * (d.op.m + 1u);
       if (need > eng->col_dwords) eng->col_dwords = need;
     }
-  // Split form: possible when the chain is [Myers adapter ops] [cuts / demultiplexing /
-  // homopolymer ops / quality trimming], which every chain cutseq/run.py compiles is.  CUTSEQ_LEAN=0/1 overrides.
+  // Split form (profiles/r03_lean_split.md): possible when the chain is [Myers adapter ops]
+  // [cuts / demultiplexing / homopolymer ops / quality trimming], which every chain cutseq/run.py compiles is.
+  // Measured SLOWER than the fused scan kernel (the finish kernel's HBM round trips cost more than the scan kernel
+  // gains), so it is opt-in: CUTSEQ_LEAN=1.  The parity suite runs the chain presets through it as well.
   {
     bool ok = plan->host.params.use_filter != 0;
     for (int mt = 0; mt < 2 && ok; ++mt) {
@@ -619,7 +621,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
       if (n > 0 && (lead == 0 || lead == n)) ok = false;  // nothing to split off / nothing left behind the scans
     }
     const char *env = getenv("CUTSEQ_LEAN");
-    eng->lean = ok && !(env && atoi(env) == 0);
+    eng->lean = ok && env && atoi(env) == 1;
   }
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;

@@ -81,6 +81,11 @@ def build_parser() -> argparse.ArgumentParser:
                    help="List all built-in adapter names and their schemes, then exit.")
     p.add_argument("--cutadapt-selection", choices=["4", "3"], default="4",
                    help="Aligner candidate selection to follow: cutadapt >= 4 (default) or 3.x (DESIGN.md section 0).")
+    p.add_argument("--ranks", type=int, default=1, metavar="N",
+                   help="Extension: one process per GPU (N processes, rank r on GPU r or on the r-th entry of "
+                        "CUTSEQ_DEVICES); the input is split at record boundaries, the output parts are concatenated "
+                        "in rank order. Output is identical to the one-process run.")
+    p.add_argument("--rank-spec", type=str, help=argparse.SUPPRESS)  # a child of --ranks: its share of the run
     p.add_argument("--demux-barcodes", type=str, metavar="FILE",
                    help="Extension: demultiplex on the 5' inline barcode. FILE lists 'name<TAB>sequence' per line (all as "
                         "long as the scheme's inline barcode); trimmed reads go to <prefix>_<name>_trimmed_R1/2.fastq.gz, "
@@ -295,7 +300,7 @@ class _DeviceWorker(threading.Thread):
             self.done.put(self)  # "this device is finished" (or failed)
 
 
-def run_pipeline(args, tp: TrimPlan) -> dict:
+def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
     """Stream the input through the GPU engine(s); returns the run statistics.
 
     Counterpart of ``runner.run(pipeline, Progress(), outfiles)`` (cutseq/run.py:473, 794): chunks of
@@ -319,7 +324,10 @@ def run_pipeline(args, tp: TrimPlan) -> dict:
     # path below (native parser / formatter in a thread pool) stays for demultiplexing runs and as CUTSEQ_TEXT_PATH=0.
     if tp.demux is None and os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
         from . import textio
-        return textio.run_text_pipeline(args, tp, devices, int(os.environ.get("CUTSEQ_CHUNK_READS", textio.CHUNK_READS)))
+        return textio.run_text_pipeline(args, tp, devices, int(os.environ.get("CUTSEQ_CHUNK_READS", textio.CHUNK_READS)),
+                                        shares=shares)
+    if shares is not None:
+        raise ValueError("--ranks needs the text path (no demultiplexing, CUTSEQ_TEXT_PATH unset)")
     chunk_reads = int(os.environ.get("CUTSEQ_CHUNK_READS", fastq.CHUNK_READS))
     paired = tp.paired
     in1 = args.input_file[0]
@@ -454,7 +462,7 @@ class ReadTooLong(ValueError):
     pass
 
 
-def run_cutseq(args):
+def run_cutseq(args, argv=None):
     barcode = BarcodeConfig(args.adapter_scheme)
     settings = settings_from_args(args)
     try:
@@ -464,7 +472,23 @@ def run_cutseq(args):
     if settings.dry_run:
         dry_run(tp, barcode)
         return None
-    totals = run_pipeline(args, tp)
+    totals = None
+    if getattr(args, "rank_spec", None):  # a child of --ranks: its share, its part files, its totals; the parent reports
+        from . import ranks
+        spec = ranks.load_spec(args.rank_spec)
+        for key, names in spec["outputs"].items():
+            setattr(args, key, names)
+        totals = run_pipeline(args, tp, shares=spec["inputs"])
+        ranks.dump_totals(spec, totals)
+        return totals
+    if getattr(args, "ranks", 1) > 1:
+        if tp.demux is not None or os.environ.get("CUTSEQ_TEXT_PATH", "1") == "0":
+            logging.warning("--ranks ignored: it needs the text path (no demultiplexing).")
+        else:
+            from . import ranks
+            totals = ranks.run_parent(list(sys.argv[1:] if argv is None else argv), args, tp)
+    if totals is None:
+        totals = run_pipeline(args, tp)
     if args.json_file:
         paired = tp.paired
         rep = report.json_report(
@@ -485,7 +509,7 @@ def main(argv: Optional[List[str]] = None):
         sys.exit(0)
     args = resolve_args(parser.parse_args(argv))
     try:
-        run_cutseq(args)
+        run_cutseq(args, argv)
     except (ReadTooLong, FileNotFoundError) as exc:  # user errors: the reference's exit style (run.py:1035-1039)
         _fail(str(exc))
 

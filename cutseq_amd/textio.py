@@ -80,9 +80,13 @@ class TextReader(threading.Thread):
     """One input file -> :class:`TextBlock` objects of exactly ``chunk_reads`` records (the last one may be shorter),
     then ``None``.  Exceptions travel through the queue."""
 
-    def __init__(self, path: str, chunk_reads: int):
+    def __init__(self, path: str, chunk_reads: int, start: int = 0, skip_lines: int = 0, max_records: Optional[int] = None):
+        """``start`` / ``skip_lines`` / ``max_records``: one rank's share of the file in the multi-process form
+        (``ranks.py``): begin at byte ``start`` (plain text) or at the gzip member that starts there, drop
+        ``skip_lines`` lines, stop behind ``max_records`` records (None = to the end of the file)."""
         super().__init__(daemon=True, name=f"cutseq-read-{os.path.basename(path)}")
         self.path, self.chunk_reads = path, chunk_reads
+        self.start_at, self.skip_lines, self.max_records = start, skip_lines, max_records
         self.blocks: "queue.Queue" = queue.Queue(maxsize=3)
         self._halt = False
         self.gz = codec.is_gzip(path)
@@ -166,14 +170,42 @@ class TextReader(threading.Thread):
         fill, lines, done = 0, 0, 0
         marks: List[tuple] = []  # (offset, nbytes, newlines) of every piece behind buf[:fill]
         eof = False
-        fd, pos, gen = -1, 0, None
+        fd, pos, gen = -1, self.start_at, None
+        skip = self.skip_lines
+        left = self.max_records  # records still to hand out (None: everything)
         if self.gz:
             src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give)
-            gen = src.blocks()
+            gen = src.blocks(self.start_at)
         else:
             fd = os.open(self.path, os.O_RDONLY)
         try:
             while not self._halt:
+                if left is not None:
+                    if left == 0:
+                        fastq.PINNED.give(buf)
+                        buf = None
+                        self._put(None)
+                        return
+                    need = 4 * min(self.chunk_reads, left)
+                while skip and not eof and lines < skip:  # (the share starts `skip` lines into its first gzip member)
+                    item = next(gen, None)
+                    if item is None:
+                        eof = True
+                        break
+                    text, nbytes = item
+                    buf = self._room(buf, fill, nbytes)
+                    C.memmove(buf.ctypes.data + fill, text.ctypes.data, nbytes)
+                    if isinstance(text.base, fastq.mmap.mmap):
+                        fastq.ARENA.give(text)
+                    lines += int(L.csh_count_newlines(buf.ctypes.data + fill, nbytes))
+                    fill += nbytes
+                if skip and lines >= skip:
+                    cut = int(L.csh_after_kth_newline(buf.ctypes.data, fill, skip))
+                    C.memmove(buf.ctypes.data, buf.ctypes.data + cut, fill - cut)
+                    fill -= cut
+                    lines -= skip
+                    marks = [(0, fill, lines)]
+                    skip = 0
                 while lines < need and not eof:
                     if gen is not None:
                         item = next(gen, None)
@@ -210,9 +242,11 @@ class TextReader(threading.Thread):
                     nxt = fastq.PINNED.take(max(buf.size, int(self.chunk_reads * est * 1.25) + 2 * _BLOCK))
                     carry = fill - cut
                     C.memmove(nxt.ctypes.data, buf.ctypes.data + cut, carry)
-                    block = TextBlock(buf, cut, self.chunk_reads, done)
-                    done += self.chunk_reads
-                    est = max(64, cut // self.chunk_reads + 1)
+                    block = TextBlock(buf, cut, need // 4, done)
+                    done += need // 4
+                    if left is not None:
+                        left -= need // 4
+                    est = max(64, cut // (need // 4) + 1)
                     buf, fill, lines = nxt, carry, lines - need
                     marks = [(0, carry, lines)]
                     _tick("cut+carry", t0)
@@ -497,16 +531,18 @@ class TextWorker(threading.Thread):
                 self.done.put(self)
 
 
-def run_text_pipeline(args, tp, devices, chunk_reads: int) -> dict:
-    """The CLI's run on the text path -> the run statistics ``report`` expects."""
+def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
+    """The CLI's run on the text path -> the run statistics ``report`` expects.  ``shares``: per input file the part
+    of it this process takes (``ranks.py``)."""
     paired = tp.paired
     in1 = args.input_file[0]
     in2 = args.input_file[1] if paired else None
-    r1 = TextReader(in1, chunk_reads)  # (a missing input file raises here, before anything else exists)
+    share = shares or [{}, {}]
+    r1 = TextReader(in1, chunk_reads, **share[0])  # (a missing input file raises here, before anything else exists)
     r2 = None
     opened: List[StreamWriter] = []
     try:
-        r2 = TextReader(in2, chunk_reads) if paired else None
+        r2 = TextReader(in2, chunk_reads, **share[1]) if paired else None
 
         def mk(names):
             group = []

@@ -215,3 +215,29 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["value"] > 0
     assert rep["config"]["parallelism"] == "shard2" and rep["config"]["pairs_per_step_per_gpu"] == 300000
     assert "cpu_baseline" not in rep  # rank 0 at N = 1 only
+
+
+def test_cli_two_ranks_equal_one_process(tmp_path, monkeypatch):
+    """--ranks 2 (two processes, both on GPU 0 here): the input split at record indices -- one mate plain text, the
+    other multi-member gzip --, every rank with its own reader, engine and output part; the concatenated output and
+    the report equal the one-process run (counterpart of make_runner(cores=N), cutseq/run.py:436, 753)."""
+    from cutseq_amd import synth
+    n = 50_000
+    batch = synth.generate_pairs(n, 150, seed=31, poly_fraction=0.05)
+    names1 = [s.encode() for s in synth.headers(n, 1)]
+    names2 = [s.encode() for s in synth.headers(n, 2)]
+    in1, in2 = str(tmp_path / "in_R1.fastq"), str(tmp_path / "in_R2.fastq.gz")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=6_000)
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "8000")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", one, "--json-file", str(tmp_path / "one.json"), in1, in2])
+    monkeypatch.setenv("CUTSEQ_DEVICES", "0,0")
+    cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", two, "--json-file", str(tmp_path / "two.json"), "--ranks", "2", in1, in2])
+    for kind in ("trimmed", "short"):
+        for mate in (1, 2):
+            assert gunzip(f"{two}_{kind}_R{mate}.fastq.gz") == gunzip(f"{one}_{kind}_R{mate}.fastq.gz"), (kind, mate)
+    a, b = json.loads((tmp_path / "one.json").read_text()), json.loads((tmp_path / "two.json").read_text())
+    assert a["read_counts"] == b["read_counts"] and a["basepair_counts"] == b["basepair_counts"]
+    assert b["read_counts"]["input"] == n and len(b["engine"]["per_device"]) == 2
+    assert not list(tmp_path.glob("*.part"))

@@ -632,3 +632,32 @@ def test_stream_writer_orders_pieces_and_releases_buffers(tmp_path, unpinned):
     w = textio.StreamWriter(str(tmp_path / "none.fq.gz"))
     w.close()
     assert gzip.decompress((tmp_path / "none.fq.gz").read_bytes()) == b""
+
+
+def test_rank_shares_reproduce_the_one_process_block_stream(tmp_path, unpinned):
+    """ranks.split_inputs: record-index shares of a plain file (no final newline) and of a multi-member gzip file, read
+    back share by share, give the same bytes and the same record counts as one reader over the whole file."""
+    from cutseq_amd import ranks, textio
+    recs1 = [b"@r%d x\n%s\n+\n%s\n" % (i, b"ACGT" * (10 + i % 30), b"IIII" * (10 + i % 30)) for i in range(40_003)]
+    recs2 = [b"@r%d y\n%s\n+\n%s\n" % (i, b"TTGA" * (5 + i % 17), b"FFFF" * (5 + i % 17)) for i in range(40_003)]
+    p1, p2 = tmp_path / "a_R1.fq", tmp_path / "a_R2.fq.gz"
+    p1.write_bytes(b"".join(recs1)[:-1])
+    with open(p2, "wb") as fh:
+        for lo in range(0, len(recs2), 3500):
+            fh.write(gzip.compress(b"".join(recs2[lo:lo + 3500]), 1))
+    shares, total = ranks.split_inputs([str(p1), str(p2)], 3)
+    assert total == 40_003 and len(shares) == 3
+    assert [s[0]["max_records"] for s in shares] == [13334, 13334, None] == [s[1]["max_records"] for s in shares]
+    for f, (path, data) in enumerate(((p1, b"".join(recs1)), (p2, b"".join(recs2)))):
+        got, sizes = b"", []
+        for r in range(3):
+            part, ns = _drain(textio.TextReader(str(path), 5000, **shares[r][f]))
+            got += part
+            sizes.append(sum(ns))
+        assert sizes == [13334, 13334, 13335]
+        assert got == data.rstrip(b"\n")
+    # one gzip member cannot be entered in the middle: the caller is told (and falls back to one process)
+    single = tmp_path / "one.fq.gz"
+    single.write_bytes(gzip.compress(b"".join(recs2), 1))
+    assert ranks.split_inputs([str(p1), str(single)], 2)[0] is None
+    assert ranks._strip_option(["-A", "X", "--ranks", "4", "a", "--ranks=2", "b"], "--ranks") == ["-A", "X", "a", "b"]
