@@ -153,10 +153,11 @@ class cs_text_result(C.Structure):
         ("route_bytes", (C.c_uint64 * 2) * 3),
         ("out_bytes", C.c_uint64 * 2),
         ("written_bp", C.c_uint64 * 2),
+        ("n_lines", C.c_uint32 * 2),
     ]
 
 
-assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 112
+assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 120
 assert C.sizeof(cs_op) == 284, C.sizeof(cs_op)
 assert C.sizeof(cs_result) == 8
 assert C.sizeof(cs_cap2) == 4

@@ -1178,6 +1178,8 @@ int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
   res->out_bytes[1] = m.out_bytes[1];
   res->written_bp[0] = m.written_bp[0];
   res->written_bp[1] = m.written_bp[1];
+  res->n_lines[0] = m.n_lines[0];
+  res->n_lines[1] = m.n_lines[1];
   if (res->error) {  // nothing to fetch: the slot is free again
     res->out_bytes[0] = res->out_bytes[1] = 0;
     s.busy = false;

@@ -184,7 +184,9 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
         for r in range(world):
             spec = {
                 "rank": r, "world": world, "inputs": shares[r],
-                "outputs": {k: [(f"{name}.rank{r}.part" if name else None) for name in names] for k, names in groups.items()},
+                # (a part keeps the ".gz" ending: the writers pick their codec by the name)
+                "outputs": {k: [(f"{name}.rank{r}.part{'.gz' if name.endswith('.gz') else ''}" if name else None) for name in names]
+                            for k, names in groups.items()},
                 "totals_file": os.path.join(work, f"totals{r}.json"),
             }
             path = os.path.join(work, f"spec{r}.json")

@@ -467,6 +467,13 @@ class TextWorker(threading.Thread):
     def _submit(self, inflight: deque, k: int, b1: TextBlock, b2: Optional[TextBlock]):
         slot = self.submitted % self.SLOTS
         self.submitted += 1
+        if os.environ.get("CUTSEQ_DEBUG_BLOCKS") == "1":  # diagnostic: what goes to the device
+            import sys
+            L = _host()
+            print(f"block {k}: slot {slot} records {b1.n}/{b2.n if b2 is not None else '-'} bytes {b1.nbytes}/"
+                  f"{b2.nbytes if b2 is not None else '-'} newlines {L.csh_count_newlines(b1.buf.ctypes.data, b1.nbytes)}/"
+                  f"{L.csh_count_newlines(b2.buf.ctypes.data, b2.nbytes) if b2 is not None else '-'} capacity {self.capacity}",
+                  file=sys.stderr, flush=True)
         self.text.submit(slot, b1.buf, b1.nbytes, b2.buf if b2 is not None else None, b2.nbytes if b2 is not None else 0, b1.n)
         inflight.append((k, slot, b1, b2))
 

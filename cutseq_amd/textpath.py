@@ -115,7 +115,9 @@ class TextEngine:
             raise TextFormatError(res.error, first_record + res.error_record,
                                   f"Input read IDs not identical in record {first_record + res.error_record + 1}")
         if res.error == abi.CS_TEXT_ERR_LINE_COUNT:
-            raise TextFormatError(res.error, first_record, "the text block does not hold the announced number of records")
+            raise TextFormatError(res.error, first_record,
+                                  f"the text block does not hold the announced number of records ({res.n_records} records, "
+                                  f"{res.n_lines[0]} / {res.n_lines[1]} line ends)")
         return res
 
     def fetch(self, slot: int, dst1, dst2=None) -> None:

@@ -291,6 +291,7 @@ typedef struct cs_text_result {
   uint64_t route_bytes[3][2]; /* [route][mate]                                                                  */
   uint64_t out_bytes[2];      /* per mate: sum over the routes = what cs_text_fetch copies                      */
   uint64_t written_bp[2];     /* per mate: bases of the records of route 0 (cutadapt's written_bp)              */
+  uint32_t n_lines[2];        /* per mate: line ends found in the text (diagnostic for CS_TEXT_ERR_LINE_COUNT)  */
 } cs_text_result;
 
 typedef struct cs_text cs_text;

@@ -240,4 +240,4 @@ def test_cli_two_ranks_equal_one_process(tmp_path, monkeypatch):
     a, b = json.loads((tmp_path / "one.json").read_text()), json.loads((tmp_path / "two.json").read_text())
     assert a["read_counts"] == b["read_counts"] and a["basepair_counts"] == b["basepair_counts"]
     assert b["read_counts"]["input"] == n and len(b["engine"]["per_device"]) == 2
-    assert not list(tmp_path.glob("*.part"))
+    assert not list(tmp_path.glob("*.part*"))
