@@ -696,6 +696,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     ENG_TRY(hipMalloc(&s.d_cap2, (size_t)max_reads * sizeof(cs_cap2)));
     ENG_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
   }
+  ENG_TRY(hipDeviceSynchronize());  // the memsets above ran on the NULL stream; the engine's streams do not wait for it
 #undef ENG_TRY
   for (int mode = 0; mode < 2; ++mode) {
     hipFuncAttributes fa;
@@ -1055,6 +1056,10 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
     TXT_TRY(hipEventCreateWithFlags(&s.formatted, hipEventDisableTiming));
     TXT_TRY(hipEventCreateWithFlags(&s.fetched, hipEventDisableTiming));
   }
+  // The hipMemset calls above run on the NULL stream and may still be in flight when this returns; the engine's
+  // streams are non-blocking (they do not wait for the NULL stream), so without this a slot's first upload could be
+  // zeroed again under the kernels that read it (seen as a flaky line-count error on a shared GPU).
+  TXT_TRY(hipDeviceSynchronize());
 #undef TXT_TRY
   *out = t;
   return CS_OK;
