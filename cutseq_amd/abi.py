@@ -11,6 +11,8 @@ CS_ABI_VERSION = 4
 CS_MAX_ADAPTER = 128
 CS_MAX_OPS = 24
 CS_MAX_STRIDE = 1536
+CS_LEN_SKIP = 0xFFFF
+CS_MAX_READ = 1 << 24
 
 CS_OP_ADAPTER, CS_OP_CUT, CS_OP_QTRIM, CS_OP_DEMUX = 1, 2, 3, 4
 CS_DEMUX_NONE = 0xFF
@@ -154,10 +156,11 @@ class cs_text_result(C.Structure):
         ("out_bytes", C.c_uint64 * 2),
         ("written_bp", C.c_uint64 * 2),
         ("n_lines", C.c_uint32 * 2),
+        ("n_long", C.c_uint32 * 2),
     ]
 
 
-assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 120
+assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 128
 assert C.sizeof(cs_op) == 284, C.sizeof(cs_op)
 assert C.sizeof(cs_result) == 8
 assert C.sizeof(cs_cap2) == 4

@@ -13,6 +13,7 @@
 #include "../../include/cutseq_hip.h"
 #include "trim_kernel.hip.inc"
 #include "finish_kernel.hip.inc"
+#include "long_kernel.hip.inc"
 #include "text_kernels.hip.inc"
 
 namespace {
@@ -913,6 +914,9 @@ struct TextSlot {
   cs_cap2 *d_cap2 = nullptr;
   uint32_t *d_dst[2] = {nullptr, nullptr};
   uint8_t *d_out[2] = {nullptr, nullptr};
+  cslong::LongRec *d_lrec[2] = {nullptr, nullptr};  // reads longer than the rows: their place in the text ...
+  cslong::LongRes *d_lres[2] = {nullptr, nullptr};  // ... and their results
+  uint32_t *d_long_of[2] = {nullptr, nullptr};      // per record: index into the two, or kNotLong
   uint32_t *d_blk = nullptr;              // block sums of the newline passes (per mate) and of the format passes
   unsigned long long *d_totals = nullptr;  // [2] line totals, [6] format column sums
   cstext::TextMeta *d_meta = nullptr;
@@ -951,7 +955,8 @@ void free_text(cs_text *t) {
     if (s.busy && s.formatted) (void)hipEventSynchronize(s.formatted);
     for (int m = 0; m < 2; ++m)
       for (void *p : {(void *)s.d_text[m], (void *)s.d_nl[m], (void *)s.d_rec[m], (void *)s.d_idr[m], (void *)s.d_seq[m],
-                      (void *)s.d_qual[m], (void *)s.d_len[m], (void *)s.d_res[m], (void *)s.d_dst[m], (void *)s.d_out[m]})
+                      (void *)s.d_qual[m], (void *)s.d_len[m], (void *)s.d_res[m], (void *)s.d_dst[m], (void *)s.d_out[m],
+                      (void *)s.d_lrec[m], (void *)s.d_lres[m], (void *)s.d_long_of[m]})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)s.d_cap2, (void *)s.d_blk, (void *)s.d_totals, (void *)s.d_meta})
       if (p) (void)hipFree(p);
@@ -1045,6 +1050,10 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
       TXT_TRY(hipMalloc(&s.d_res[m], (size_t)max_records * sizeof(cs_result)));
       TXT_TRY(hipMalloc(&s.d_dst[m], (size_t)max_records * sizeof(uint32_t)));
       TXT_TRY(hipMalloc(&s.d_out[m], out_cap));
+      TXT_TRY(hipMalloc(&s.d_lrec[m], (size_t)max_records * sizeof(cslong::LongRec)));
+      TXT_TRY(hipMalloc(&s.d_lres[m], (size_t)max_records * sizeof(cslong::LongRes)));
+      TXT_TRY(hipMalloc(&s.d_long_of[m], (size_t)max_records * sizeof(uint32_t)));
+      TXT_TRY(hipMemset(s.d_long_of[m], 0xff, (size_t)max_records * sizeof(uint32_t)));
     }
     if (t->needs_cap2) TXT_TRY(hipMalloc(&s.d_cap2, (size_t)max_records * sizeof(cs_cap2)));
     const size_t blk = (size_t)2 * (t->seg_blocks + 1) + (size_t)6 * (t->fmt_blocks + 1);
@@ -1101,7 +1110,8 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
       hipLaunchKernelGGL(cstext::text_write_nl, dim3(nb), dim3(cstext::kSegThreads), 0, st, s.d_text[m], (uint32_t)bytes[m],
                          blk_nl[m], s.d_totals + m, 4u * n_records, s.d_nl[m], s.d_meta, m);
       hipLaunchKernelGGL(cstext::text_parse_records, dim3((n_records + 255u) / 256u), dim3(256), 0, st, s.d_text[m],
-                         s.d_nl[m], n_records, t->stride, t->tp, m, s.d_rec[m], s.d_idr[m], s.d_len[m], s.d_meta);
+                         s.d_nl[m], n_records, t->stride, t->tp, m, s.d_rec[m], s.d_idr[m], s.d_len[m], s.d_lrec[m],
+                         s.d_long_of[m], s.d_meta);
     }
     if (mates == 2)
       hipLaunchKernelGGL(cstext::text_check_pairs, dim3((n_records + 255u) / 256u), dim3(256), 0, st, s.d_text[0], s.d_rec[0],
@@ -1111,6 +1121,21 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
       const uint32_t grid = (uint32_t)((dwords + 255ull) / 256ull > 65536ull ? 65536ull : (dwords + 255ull) / 256ull);
       hipLaunchKernelGGL(cstext::text_restride, dim3(grid), dim3(256), 0, st, s.d_text[m], s.d_rec[m], n_records, t->stride / 4,
                          reinterpret_cast<uint32_t *>(s.d_seq[m]), reinterpret_cast<uint32_t *>(s.d_qual[m]));
+    }
+    // reads that do not fit the rows walk their chain in a kernel of their own (usually there are none); in front of
+    // the scan kernel, so that "scan kernel done" covers them for the streams that wait on it
+    for (int m = 0; m < mates; ++m) {
+      cslong::LongArgs la;
+      la.text = s.d_text[m];
+      la.rec = s.d_lrec[m];
+      la.res = s.d_lres[m];
+      la.n_long = &s.d_meta->n_long[m];
+      la.cap = n_records;
+      la.stats = eng->d_stats + (size_t)m * csdev::kStatWords;
+      la.plan_slot = (uint32_t)eng->plan_slot;
+      la.mate = m;
+      la.gate = &s.d_meta->err;
+      hipLaunchKernelGGL(cslong::long_kernel, dim3(256), dim3(64), 0, st, la);
     }
     HIP_TRY(hipGetLastError());
     cs_reads rd[2];
@@ -1135,6 +1160,9 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
       fa.res[m] = s.d_res[m];
       fa.dst[m] = s.d_dst[m];
       fa.out[m] = s.d_out[m];
+      fa.long_of[m] = s.d_long_of[m];
+      fa.lrec[m] = s.d_lrec[m];
+      fa.lres[m] = s.d_lres[m];
     }
     fa.cap2 = s.d_cap2;
     fa.n = n_records;
@@ -1185,6 +1213,8 @@ int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
   res->written_bp[1] = m.written_bp[1];
   res->n_lines[0] = m.n_lines[0];
   res->n_lines[1] = m.n_lines[1];
+  res->n_long[0] = m.n_long[0];
+  res->n_long[1] = m.n_long[1];
   if (res->error) {  // nothing to fetch: the slot is free again
     res->out_bytes[0] = res->out_bytes[1] = 0;
     s.busy = false;

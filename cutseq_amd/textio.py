@@ -437,7 +437,7 @@ class TextWorker(threading.Thread):
         self.tp, self.device, self.done, self.chunk_reads = tp, device, done, chunk_reads
         self.inbox: "queue.Queue" = queue.Queue(maxsize=self.SLOTS)
         self.engine = self.text = None
-        self.stride, self.capacity = 152, 0
+        self.stride, self.capacity, self.want_stride = 152, 0, 152
         self.stats = None
         self.error: Optional[BaseException] = None
         self.submitted = 0
@@ -448,7 +448,7 @@ class TextWorker(threading.Thread):
 
     def _ensure(self, inflight: deque, text_bytes: int, stride: Optional[int] = None):
         """The text engine, rebuilt for longer rows or bigger blocks -- after everything in flight came back."""
-        stride = stride or self.stride
+        stride = max(stride or self.stride, self.want_stride)
         if self.text is not None and stride <= self.stride and text_bytes <= self.capacity:
             return
         from .engine import TrimEngine
@@ -483,19 +483,17 @@ class TextWorker(threading.Thread):
         try:
             res = self.text.wait(slot, first_record=b1.first_record)
             t0 = _tick("wait", t0)
-        except textpath.ReadLongerThanStride as exc:
-            # rows too short for this batch: everything else comes back first, then longer rows and once more
-            if exc.longest > abi.CS_MAX_STRIDE:
-                from .run import ReadTooLong
-                raise ReadTooLong(f"reads longer than {abi.CS_MAX_STRIDE} nt are not supported by the GPU tile "
-                                  f"(a read of {exc.longest} nt in records {b1.first_record + 1}..{b1.first_record + b1.n})")
-            self._ensure(inflight, max(b1.nbytes, b2.nbytes if b2 is not None else 0), stride=(exc.longest + 3) // 4 * 4)
-            self._submit(inflight, k, b1, b2)
-            return self._finish(inflight)
+        except textpath.ReadTooLong as exc:
+            from .run import ReadTooLong
+            raise ReadTooLong(f"{exc} in records {b1.first_record + 1}..{b1.first_record + b1.n}")
         except textpath.TextFormatError as exc:
             if exc.code == abi.CS_TEXT_ERR_IDS_DIFFER:
                 raise ValueError(str(exc))
             raise fastq.FastqFormatError(str(exc))
+        # Reads longer than the rows took the exact but slow long-read kernel.  A library whose reads are simply longer
+        # than the rows so far (2 x 250, 2 x 300) should not stay there: longer rows from the next batch on.
+        if max(res.n_long) * 64 > b1.n and self.stride < abi.CS_MAX_STRIDE:
+            self.want_stride = max(self.want_stride, min(abi.CS_MAX_STRIDE, (int(res.max_len) + 3) // 4 * 4))
         out = [fastq.PINNED.take(max(int(res.out_bytes[m]), 1)) for m in range(2 if b2 is not None else 1)]
         t0 = _tick("take", t0)
         self.text.fetch(slot, out[0], out[1] if b2 is not None else None)

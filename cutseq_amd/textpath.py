@@ -28,9 +28,11 @@ class TextFormatError(ValueError):
         self.code, self.record = code, record
 
 
-class ReadLongerThanStride(Exception):
+class ReadTooLong(ValueError):
+    """A read beyond CS_MAX_READ (the text path's positions are 32-bit, its long-read kernel serial per read)."""
+
     def __init__(self, longest: int):
-        super().__init__(f"a read of {longest} nt does not fit the row stride")
+        super().__init__(f"reads longer than {abi.CS_MAX_READ} nt are not supported (a read of {longest} nt)")
         self.longest = longest
 
 
@@ -102,11 +104,11 @@ class TextEngine:
 
     def wait(self, slot: int, first_record: int = 0, names=("mate 1", "mate 2")) -> abi.cs_text_result:
         """Blocks until the batch is formatted on the device.  Raises what the reference's reader would raise for a
-        bad record; :class:`ReadLongerThanStride` asks the caller to rebuild with longer rows and resubmit."""
+        bad record.  Reads longer than the rows are not an error: they took the long-read kernel (``res.n_long``)."""
         res = abi.cs_text_result()
         capi.check(self.L.cs_text_wait(self._h, slot, C.byref(res)))
         if res.error == abi.CS_TEXT_ERR_TOO_LONG:
-            raise ReadLongerThanStride(int(res.max_len))
+            raise ReadTooLong(int(res.max_len))
         if res.error == abi.CS_TEXT_ERR_MALFORMED:
             raise TextFormatError(res.error, first_record + res.error_record,
                                   f"malformed FASTQ record {first_record + res.error_record + 1} "

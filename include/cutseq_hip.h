@@ -31,6 +31,9 @@ extern "C" {
 #define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
 #define CS_MAX_OPS 24      /* longest per-mate op chain                           */
 #define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
+#define CS_LEN_SKIP 0xFFFF /* cs_reads.len[i]: the kernels pass over this read (no result, not counted); the text path
+                              marks reads longer than the rows this way and walks their chain in a kernel of their own */
+#define CS_MAX_READ (1u << 24) /* longest read the text path takes (cs_text_*): positions are 32-bit there */
 
 typedef enum cs_status {
   CS_OK = 0,
@@ -266,7 +269,7 @@ int cs_kernel_time_totals(cs_engine *eng, uint32_t *calls, float ms[2], int rese
 enum {
   CS_TEXT_OK = 0,
   CS_TEXT_ERR_MALFORMED = 1,   /* no '@' / '+' line, sequence and quality lengths differ: record `error_record` */
-  CS_TEXT_ERR_TOO_LONG = 2,    /* a read is longer than the row stride: rebuild with `max_len` and resubmit    */
+  CS_TEXT_ERR_TOO_LONG = 2,    /* a read is longer than CS_MAX_READ                                            */
   CS_TEXT_ERR_IDS_DIFFER = 3,  /* PairedEndRenamer: "Input read IDs not identical" at record `error_record`    */
   CS_TEXT_ERR_LINE_COUNT = 4   /* the text does not hold 4 * n_records lines                                   */
 };
@@ -292,6 +295,7 @@ typedef struct cs_text_result {
   uint64_t out_bytes[2];      /* per mate: sum over the routes = what cs_text_fetch copies                      */
   uint64_t written_bp[2];     /* per mate: bases of the records of route 0 (cutadapt's written_bp)              */
   uint32_t n_lines[2];        /* per mate: line ends found in the text (diagnostic for CS_TEXT_ERR_LINE_COUNT)  */
+  uint32_t n_long[2];         /* per mate: reads longer than the rows (they took the slow, exact kernel)         */
 } cs_text_result;
 
 typedef struct cs_text cs_text;

@@ -4,6 +4,8 @@ string-level restatement."""
 import gzip
 import json
 
+import numpy as np
+
 import pytest
 
 from cutseq_amd import plan as planmod, run as cli
@@ -179,16 +181,59 @@ def test_cli_longer_reads_appear_in_a_later_chunk(tmp_path, monkeypatch):
     assert rep["basepair_counts"]["quality_trimmed_read1"] == int(s1.qualtrim_bp)
 
 
-def test_cli_read_longer_than_the_tile_is_a_user_error(tmp_path, caplog):
-    """Reads beyond CS_MAX_STRIDE (1536 nt) are refused the way the reference refuses bad input:
-    logging.error + exit status 1 (cutseq/run.py:1035-1039), not a traceback."""
-    seq = "ACGT" * 500
-    p = tmp_path / "long.fq"
-    p.write_text(f"@x\n{seq}\n+\n{'I' * len(seq)}\n")
-    with pytest.raises(SystemExit) as exc:
-        cli.main([str(p), "-A", "TAKARAV3", "-o", str(tmp_path / "o.fq"), "-s", str(tmp_path / "s.fq")])
-    assert exc.value.code == 1
-    assert "1536" in caplog.text
+def test_cli_reads_of_any_length(tmp_path, monkeypatch):
+    """The reference streams records of any length (cutseq/run.py:434, 751).  5 k / 20 k / 1 537-nt reads mixed into a
+    150-nt library: the long ones leave the tile kernels' rows and walk their chain in the long-read kernel, the
+    output (all three routes) equals the oracle's through the record logic; also a mate pair where only ONE mate
+    is long, adapters inside long reads, poly tails and quality tails on them."""
+    from cutseq_amd import synth
+    from cutseq_amd.common import reverse_complement as rc
+    rng = np.random.default_rng(17)
+    n = 3000
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    bc = tp  # noqa: F841
+    base = synth.generate_pairs(n, 150, seed=41, poly_fraction=0.05)
+    p7, p5rc = "AGATCGGAAGAGCACACGTC", rc("ACACGACGCTCTTCCGATCT")
+    reads1 = [(util.row_bytes(base.seq1, base.len1, i).decode(), util.row_bytes(base.qual1, base.len1, i).decode()) for i in range(n)]
+    reads2 = [(util.row_bytes(base.seq2, base.len2, i).decode(), util.row_bytes(base.qual2, base.len2, i).decode()) for i in range(n)]
+
+    def dna(k):
+        return "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+
+    def quals(k, tail):
+        return "I" * (k - tail) + "#" * tail
+
+    specials = {
+        5: (dna(5000), dna(5000)),                                                  # nothing to find in 5 kb
+        700: (dna(12000) + "TTT" + dna(8) + p7 + dna(300), dna(14) + dna(400)),     # 3' adapter deep inside a 12 kb read; mate short
+        701: (dna(150), "T" * 30 + dna(20000) + p5rc[:13]),                         # only mate 2 long: poly-T head, partial adapter at the end
+        1500: (dna(1537), dna(1600)),                                               # just over the tile limit
+        2999: (dna(3) + dna(2500) + "A" * 60 + dna(14) + p7, dna(8) + dna(6) + dna(2500)),
+    }
+    for i, (a, b) in specials.items():
+        reads1[i] = (a, quals(len(a), 40 if i % 2 else 0))
+        reads2[i] = (b, quals(len(b), 0 if i % 2 else 25))
+    batch = util.batch_from_reads(reads1, reads2)
+    names1 = [f"r{i} 1:N".encode() for i in range(n)]
+    names2 = [f"r{i} 2:N".encode() for i in range(n)]
+    in1, in2 = str(tmp_path / "a_R1.fq"), str(tmp_path / "a_R2.fq")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2)
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "1000")
+    prefix = str(tmp_path / "o")
+    cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", prefix, "--json-file", str(tmp_path / "r.json"), in1, in2])
+    want = oracle_streams(tp, batch, names1, names2)
+    want.pop("untrimmed")
+    got = read_streams(prefix, True)
+    assert crc_streams(got) == crc_streams(want)
+    rep = json.loads((tmp_path / "r.json").read_text())
+    (o1, _, s1), (o2, _, s2) = util.oracle_run(tp, batch)
+    assert rep["read_counts"]["input"] == n
+    assert rep["basepair_counts"]["input_read1"] == int(batch.len1.sum()) and rep["basepair_counts"]["input_read2"] == int(batch.len2.sum())
+    assert rep["basepair_counts"]["quality_trimmed_read1"] == int(s1.qualtrim_bp)
+    assert int(o1["stop"][700]) < 12100 and int(o1["flags"][700]) & 2  # the adapter inside the 12 kb read was found
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu():

@@ -163,11 +163,10 @@ def test_text_path_errors_are_the_readers_errors():
             with pytest.raises(textpath.TextFormatError) as e:
                 te.run(good1[: len(good1) // 2 + 3], 2, good2)
             assert e.value.code in (abi.CS_TEXT_ERR_LINE_COUNT, abi.CS_TEXT_ERR_MALFORMED)
-            # a read longer than the rows: the caller is told how long, nothing is written
-            long1 = b"@r1 1\n" + b"A" * 40 + b"\n+\n" + b"I" * 40 + b"\n"
-            with pytest.raises(textpath.ReadLongerThanStride) as e:
-                te.run(long1, 1, b"@r1 2\nACGT\n+\nIIII\n")
-            assert e.value.longest == 40
+            # a read longer than the rows (12 here) is no error: it takes the long-read kernel
+            long1 = b"@r1 1\n" + b"ACGTTGCA" * 5 + b"\n+\n" + b"I" * 40 + b"\n"
+            s_long, c_long = te.run(long1, 1, b"@r1 2\nACGT\n+\nIIII\n")
+            assert sum(c_long) == 1 and b"ACGTTGCA" in b"".join(x[0] for x in s_long)
             # the engine is still usable afterwards
             streams2, counts2 = te.run(good1, 2, good2)
             assert streams2 == streams and counts2 == counts
