@@ -137,7 +137,7 @@ class cs_text_params(C.Structure):
         ("has_umi", C.c_uint8),
         ("untrimmed_filter", C.c_uint8),
         ("reverse_complement", C.c_uint8),
-        ("_pad", C.c_uint8),
+        ("compress", C.c_uint8),
         ("max_tag", C.c_uint32),
         ("suffix1", C.c_char_p * 2),
         ("suffix2", C.c_char_p * 2),
@@ -157,10 +157,11 @@ class cs_text_result(C.Structure):
         ("written_bp", C.c_uint64 * 2),
         ("n_lines", C.c_uint32 * 2),
         ("n_long", C.c_uint32 * 2),
+        ("text_bytes", (C.c_uint64 * 2) * 3),
     ]
 
 
-assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 128
+assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 176
 assert C.sizeof(cs_op) == 284, C.sizeof(cs_op)
 assert C.sizeof(cs_result) == 8
 assert C.sizeof(cs_cap2) == 4

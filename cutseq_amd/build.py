@@ -10,7 +10,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 SRC = HERE / "csrc" / "cutseq_hip.hip"
 DEPS = [SRC, HERE / "csrc" / "trim_kernel.hip.inc", HERE / "csrc" / "finish_kernel.hip.inc", HERE / "csrc" / "long_kernel.hip.inc",
-        HERE / "csrc" / "text_kernels.hip.inc",
+        HERE / "csrc" / "text_kernels.hip.inc", HERE / "csrc" / "deflate_kernels.hip.inc",
         HERE.parent / "include" / "cutseq_hip.h"]
 OUT = HERE / "libcutseq_hip.so"
 

@@ -15,6 +15,7 @@
 #include "finish_kernel.hip.inc"
 #include "long_kernel.hip.inc"
 #include "text_kernels.hip.inc"
+#include "deflate_kernels.hip.inc"
 
 namespace {
 
@@ -917,6 +918,10 @@ struct TextSlot {
   cslong::LongRec *d_lrec[2] = {nullptr, nullptr};  // reads longer than the rows: their place in the text ...
   cslong::LongRes *d_lres[2] = {nullptr, nullptr};  // ... and their results
   uint32_t *d_long_of[2] = {nullptr, nullptr};      // per record: index into the two, or kNotLong
+  uint8_t *d_gzstage[2] = {nullptr, nullptr};       // compressed output: one slot per 32 KB chunk ...
+  uint8_t *d_gz[2] = {nullptr, nullptr};            // ... laid out as gzip members
+  csdefl::ChunkInfo *d_chunk[2] = {nullptr, nullptr};
+  uint32_t *d_chunk_dst[2] = {nullptr, nullptr};
   uint32_t *d_blk = nullptr;              // block sums of the newline passes (per mate) and of the format passes
   unsigned long long *d_totals = nullptr;  // [2] line totals, [6] format column sums
   cstext::TextMeta *d_meta = nullptr;
@@ -935,6 +940,8 @@ struct cs_text {
   uint32_t max_records = 0, stride = 0, max_tag = 0;
   uint32_t seg_blocks = 0, fmt_blocks = 0;
   bool needs_cap2 = false;
+  bool compress = false;      // the output streams leave the device as gzip members
+  uint32_t max_chunks = 0;
   hipStream_t h2d = nullptr, d2h = nullptr;
   std::vector<TextSlot> slots;
 };
@@ -956,7 +963,8 @@ void free_text(cs_text *t) {
     for (int m = 0; m < 2; ++m)
       for (void *p : {(void *)s.d_text[m], (void *)s.d_nl[m], (void *)s.d_rec[m], (void *)s.d_idr[m], (void *)s.d_seq[m],
                       (void *)s.d_qual[m], (void *)s.d_len[m], (void *)s.d_res[m], (void *)s.d_dst[m], (void *)s.d_out[m],
-                      (void *)s.d_lrec[m], (void *)s.d_lres[m], (void *)s.d_long_of[m]})
+                      (void *)s.d_lrec[m], (void *)s.d_lres[m], (void *)s.d_long_of[m], (void *)s.d_gzstage[m], (void *)s.d_gz[m],
+                      (void *)s.d_chunk[m], (void *)s.d_chunk_dst[m]})
         if (p) (void)hipFree(p);
     for (void *p : {(void *)s.d_cap2, (void *)s.d_blk, (void *)s.d_totals, (void *)s.d_meta})
       if (p) (void)hipFree(p);
@@ -1015,6 +1023,8 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
     }
   // a second capture exists only in single-end chains (cs_cap2)
   t->needs_cap2 = !eng->paired && params->has_umi;
+  t->compress = params->compress != 0;
+  t->max_chunks = (uint32_t)((out_cap + csdefl::kChunk - 1) / csdefl::kChunk) + 3u;
   t->seg_blocks = (uint32_t)((max_text_bytes + cstext::kSeg - 1) / cstext::kSeg);
   t->fmt_blocks = (max_records + 255u) / 256u;
 #define TXT_TRY(expr)                                                                       \
@@ -1027,6 +1037,29 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
     }                                                                                       \
   } while (0)
   TXT_TRY(hipSetDevice(eng->device));
+  if (t->compress) {
+    // constants of the CRC-32 combination (zlib's x2n_table; shifts by whole 128-byte slices)
+    auto mult = [](uint32_t a, uint32_t b) {
+      uint32_t m = 1u << 31, p = 0;
+      for (;;) {
+        if (a & m) {
+          p ^= b;
+          if ((a & (m - 1u)) == 0u) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ csdefl::kPoly : b >> 1;
+      }
+      return p;
+    };
+    uint32_t x2n[32], shift[256];
+    x2n[0] = 1u << 30;
+    for (int i = 1; i < 32; ++i) x2n[i] = mult(x2n[i - 1], x2n[i - 1]);
+    const uint32_t step = x2n[10];  // x^(2^10) = x^(8 * 128)
+    shift[0] = 1u << 31;
+    for (int i = 1; i < 256; ++i) shift[i] = mult(shift[i - 1], step);
+    TXT_TRY(hipMemcpyToSymbol(HIP_SYMBOL(csdefl::c_x2n), x2n, sizeof x2n));
+    TXT_TRY(hipMemcpyToSymbol(HIP_SYMBOL(csdefl::c_shift128), shift, sizeof shift));
+  }
   TXT_TRY(hipStreamCreateWithFlags(&t->h2d, hipStreamNonBlocking));
   TXT_TRY(hipStreamCreateWithFlags(&t->d2h, hipStreamNonBlocking));
   t->slots.resize(n_slots);
@@ -1054,6 +1087,12 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
       TXT_TRY(hipMalloc(&s.d_lres[m], (size_t)max_records * sizeof(cslong::LongRes)));
       TXT_TRY(hipMalloc(&s.d_long_of[m], (size_t)max_records * sizeof(uint32_t)));
       TXT_TRY(hipMemset(s.d_long_of[m], 0xff, (size_t)max_records * sizeof(uint32_t)));
+      if (t->compress) {
+        TXT_TRY(hipMalloc(&s.d_gzstage[m], (size_t)t->max_chunks * csdefl::kSlot));
+        TXT_TRY(hipMalloc(&s.d_gz[m], (size_t)t->max_chunks * csdefl::kSlot + 64));
+        TXT_TRY(hipMalloc(&s.d_chunk[m], (size_t)t->max_chunks * sizeof(csdefl::ChunkInfo)));
+        TXT_TRY(hipMalloc(&s.d_chunk_dst[m], (size_t)t->max_chunks * sizeof(uint32_t)));
+      }
     }
     if (t->needs_cap2) TXT_TRY(hipMalloc(&s.d_cap2, (size_t)max_records * sizeof(cs_cap2)));
     const size_t blk = (size_t)2 * (t->seg_blocks + 1) + (size_t)6 * (t->fmt_blocks + 1);
@@ -1178,6 +1217,36 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
     const unsigned long long want = (items * 32ull + 255ull) / 256ull;
     hipLaunchKernelGGL(cstext::format_copy, dim3((uint32_t)(want > 32768ull ? 32768ull : want)), dim3(256), 0, rs, fa, t->tp);
     HIP_TRY(hipGetLastError());
+    if (t->compress) {
+      for (int m = 0; m < mates; ++m) {
+        csdefl::DeflateArgs da;
+        da.text = s.d_out[m];
+        da.route_bytes = &s.d_meta->route_bytes[0][m];
+        da.stage = s.d_gzstage[m];
+        da.info = s.d_chunk[m];
+        da.max_chunks = t->max_chunks;
+        da.gate = &s.d_meta->err;
+        hipLaunchKernelGGL(csdefl::deflate_chunks, dim3(t->max_chunks), dim3(256), 0, rs, da);
+        csdefl::LayoutArgs la;
+        la.info = s.d_chunk[m];
+        la.route_bytes = da.route_bytes;
+        la.chunk_dst = s.d_chunk_dst[m];
+        la.gz = s.d_gz[m];
+        la.gz_route_bytes = &s.d_meta->gz_route_bytes[0][m];
+        la.gz_total = &s.d_meta->gz_bytes[m];
+        la.gate = da.gate;
+        hipLaunchKernelGGL(csdefl::deflate_layout, dim3(1), dim3(64), 0, rs, la);
+        csdefl::CompactArgs ca;
+        ca.info = s.d_chunk[m];
+        ca.chunk_dst = s.d_chunk_dst[m];
+        ca.stage = s.d_gzstage[m];
+        ca.gz = s.d_gz[m];
+        ca.route_bytes = da.route_bytes;
+        ca.gate = da.gate;
+        hipLaunchKernelGGL(csdefl::deflate_compact, dim3(t->max_chunks), dim3(256), 0, rs, ca);
+      }
+      HIP_TRY(hipGetLastError());
+    }
   } else {
     HIP_TRY(hipEventRecord(s.fetched, st));  // order the resolve stream behind the (empty) batch's meta
     HIP_TRY(hipStreamWaitEvent(rs, s.fetched, 0));
@@ -1209,6 +1278,15 @@ int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
   }
   res->out_bytes[0] = m.out_bytes[0];
   res->out_bytes[1] = m.out_bytes[1];
+  if (t->compress && m.err == ~0ull) {  // what is fetched (and written) are the gzip members
+    for (int q = 0; q < 3; ++q)
+      for (int k = 0; k < 2; ++k) {
+        res->text_bytes[q][k] = m.route_bytes[q][k];
+        res->route_bytes[q][k] = m.gz_route_bytes[q][k];
+      }
+    res->out_bytes[0] = m.gz_bytes[0];
+    res->out_bytes[1] = m.gz_bytes[1];
+  }
   res->written_bp[0] = m.written_bp[0];
   res->written_bp[1] = m.written_bp[1];
   res->n_lines[0] = m.n_lines[0];
@@ -1231,10 +1309,10 @@ int cs_text_fetch(cs_text *t, uint32_t slot, void *dst1, void *dst2) {
   HIP_TRY(hipSetDevice(t->eng->device));
   void *dst[2] = {dst1, dst2};
   for (int m = 0; m < (t->eng->paired ? 2 : 1); ++m) {
-    const size_t bytes = (size_t)s.h_meta->out_bytes[m];
+    const size_t bytes = (size_t)(t->compress ? s.h_meta->gz_bytes[m] : s.h_meta->out_bytes[m]);
     if (!bytes) continue;
     if (!dst[m]) return fail(CS_ERR_ARG, "mate %d: %zu bytes of output and no buffer", m + 1, bytes);
-    HIP_TRY(hipMemcpyAsync(dst[m], s.d_out[m], bytes, hipMemcpyDeviceToHost, t->d2h));
+    HIP_TRY(hipMemcpyAsync(dst[m], t->compress ? s.d_gz[m] : s.d_out[m], bytes, hipMemcpyDeviceToHost, t->d2h));
   }
   HIP_TRY(hipEventRecord(s.fetched, t->d2h));
   HIP_TRY(hipEventSynchronize(s.fetched));

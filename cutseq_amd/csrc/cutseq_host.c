@@ -625,3 +625,55 @@ int64_t csh_after_kth_newline(const uint8_t *buf, int64_t n, int64_t k) {
   }
   return -1;
 }
+
+/* ===========================================================================================
+ * gzip members around device-compressed deflate data (cs_text_* with compression): the device returns
+ * one CRC-32 per 32 KB chunk; the member's CRC-32 is their combination (zlib's crc32_combine,
+ * restated: multiplication by x^(8 len) modulo the reflected polynomial).
+ * =========================================================================================== */
+#define CSH_CRC_POLY 0xedb88320u
+
+static uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+  uint32_t m = 1u << 31, p = 0;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1)) == 0) break;
+    }
+    m >>= 1;
+    b = (b & 1) ? (b >> 1) ^ CSH_CRC_POLY : b >> 1;
+  }
+  return p;
+}
+
+/* x^(n * 2^k) modulo p */
+static uint32_t crc_x2nmodp(uint64_t n, unsigned k) {
+  static uint32_t table[32];
+  static int ready = 0;
+  if (!ready) {
+    uint32_t p = 1u << 30; /* x^1 */
+    table[0] = p;
+    for (int i = 1; i < 32; i++) table[i] = p = crc_multmodp(p, p);
+    ready = 1;
+  }
+  uint32_t p = 1u << 31; /* x^0 */
+  while (n) {
+    if (n & 1) p = crc_multmodp(table[k & 31], p);
+    n >>= 1;
+    k++;
+  }
+  return p;
+}
+
+/* CRC-32 of the concatenation of n pieces with CRCs crc[i] and lengths len[i] (bytes) */
+uint32_t csh_crc32_combine_many(const uint32_t *crc, const uint32_t *len, int64_t n) {
+  uint32_t total = 0;
+  for (int64_t i = 0; i < n; i++) total = crc_multmodp(crc_x2nmodp(len[i], 3), total) ^ crc[i];
+  return total;
+}
+
+/* the 256 constants x^(8 * bytes) for bytes = piece * step, piece = 0 .. 255: what a device thread multiplies the
+ * CRC of its slice by to move it `bytes` towards the front (cutseq_hip.hip uploads the table once per engine) */
+void csh_crc32_shift_table(uint32_t *out, uint32_t step) {
+  for (uint32_t i = 0; i < 256; i++) out[i] = crc_x2nmodp((uint64_t)i * step, 3);
+}

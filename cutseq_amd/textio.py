@@ -318,11 +318,13 @@ class StreamWriter:
     of about 4 MB, compressed in the pool (level 1 = cutadapt's default; any split of the text is a valid gzip
     file and decompresses to the same bytes); plain: big pieces are written with several ``pwrite`` calls at once."""
 
-    def __init__(self, path: str, level: int = 1):
+    def __init__(self, path: str, level: int = 1, precompressed: bool = False):
+        """``precompressed``: what arrives are finished gzip members (the device compressed them): written as they are."""
         self.path, self.level, self.gz = path, level, path.endswith(".gz")
+        self.precompressed = precompressed and self.gz
         self.fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
         self.pos = 0
-        self.mappable = not self.gz
+        self.mappable = True
         self.q: "queue.Queue" = queue.Queue()
         self.err: Optional[BaseException] = None
         self.t = threading.Thread(target=self._run, daemon=True, name=f"cutseq-write-{os.path.basename(path)}")
@@ -332,7 +334,7 @@ class StreamWriter:
         if self.err is not None:
             shared.done()
             raise self.err
-        if self.gz:
+        if self.gz and not self.precompressed:
             pool = fastq._pool()
             futs = [pool.submit(codec.gzip_member, view[lo:lo + _GZ_PIECE], self.level) for lo in range(0, len(view), _GZ_PIECE)]
             self.q.put((futs, shared))
@@ -432,9 +434,9 @@ class TextWorker(threading.Thread):
 
     SLOTS = 3
 
-    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int):
+    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int, compress: bool = False):
         super().__init__(daemon=True, name=f"cutseq-gpu{device}")
-        self.tp, self.device, self.done, self.chunk_reads = tp, device, done, chunk_reads
+        self.tp, self.device, self.done, self.chunk_reads, self.compress = tp, device, done, chunk_reads, compress
         self.inbox: "queue.Queue" = queue.Queue(maxsize=self.SLOTS)
         self.engine = self.text = None
         self.stride, self.capacity, self.want_stride = 152, 0, 152
@@ -461,7 +463,7 @@ class TextWorker(threading.Thread):
         self.stride = max(self.stride, stride)
         self.capacity = max(self.capacity, int(text_bytes * 1.25) + (1 << 20))
         self.text = textpath.TextEngine(self.engine, slots=self.SLOTS, max_text_bytes=self.capacity,
-                                        max_records=self.chunk_reads, stride=self.stride)
+                                        max_records=self.chunk_reads, stride=self.stride, compress=self.compress)
         self.submitted = 0
 
     def _submit(self, inflight: deque, k: int, b1: TextBlock, b2: Optional[TextBlock]):
@@ -549,10 +551,15 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
     try:
         r2 = TextReader(in2, chunk_reads, **share[1]) if paired else None
 
+        # every output a ".gz" file: the device compresses (deflate_kernels.hip.inc) and the writers pass the members
+        # through; otherwise text comes back and ".gz" outputs are deflated in the host pool (CUTSEQ_GPU_DEFLATE=0 too)
+        names_all = [n for group in (args.output_file, args.short_file, args.untrimmed_file) for n in group if n]
+        compress = bool(names_all) and all(n.endswith(".gz") for n in names_all) and os.environ.get("CUTSEQ_GPU_DEFLATE", "1") != "0"
+
         def mk(names):
             group = []
             for n in names:
-                group.append(StreamWriter(n) if n else None)
+                group.append(StreamWriter(n, precompressed=compress) if n else None)
                 if group[-1] is not None:
                     opened.append(group[-1])
             return group
@@ -574,7 +581,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
     totals = report.new_totals()
     t_start = time.perf_counter()
     done: "queue.Queue" = queue.Queue()
-    workers = [TextWorker(tp, dev, done, chunk_reads) for dev in devices]
+    workers = [TextWorker(tp, dev, done, chunk_reads, compress) for dev in devices]
     budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk
     failure: List[BaseException] = []
 

@@ -65,7 +65,9 @@ class TextEngine:
     """``slots`` batches in flight on one :class:`TrimEngine` (its plan, streams and statistics block)."""
 
     def __init__(self, engine: TrimEngine, slots: int = 3, max_text_bytes: int = 64 << 20, max_records: int = 1 << 18,
-                 stride: int = 152):
+                 stride: int = 152, compress: bool = False):
+        """``compress``: every route's output leaves the device as one gzip member (``res.route_bytes`` then counts
+        compressed bytes): what ``.gz`` output files take as they are."""
         self.L = capi.load()
         self.engine = engine
         plan = engine.plan
@@ -74,6 +76,8 @@ class TextEngine:
         p.has_umi = 1 if plan.has_umi else 0
         p.untrimmed_filter = 1 if plan.untrimmed_filter else 0
         p.reverse_complement = 1 if plan.reverse_complement else 0
+        p.compress = 1 if compress else 0
+        self.compress = bool(compress)
         p.max_tag = max_tag(plan)
         self._keep = []  # the literals must outlive the call
         for field, chain in (("suffix1", plan.r1), ("suffix2", plan.r2)):

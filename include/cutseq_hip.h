@@ -278,7 +278,9 @@ typedef struct cs_text_params {
   uint8_t has_umi;            /* Renamer template carries the captures: {id}_{cut_prefix}{cut_suffix}           */
   uint8_t untrimmed_filter;   /* IsUntrimmedAny filter installed (run.py:453-467, 771-784)                      */
   uint8_t reverse_complement; /* single-end --auto-rc on a '-' library (run.py:420-426)                         */
-  uint8_t _pad;
+  uint8_t compress;           /* 1: every route's output leaves the device as ONE gzip member (32 KB deflate blocks,
+                                 dynamic Huffman codes, no LZ77 stage; the counterpart of xopen's level-1 writer the
+                                 reference's OutputFiles use): route_bytes / out_bytes then count compressed bytes    */
   uint32_t max_tag;           /* most bytes a record name can gain: 1 + the plan's capture lengths (0 = no UMI) */
   const char *suffix1[2];     /* SuffixRemover literals of mate 1, applied in order (NULL = none)               */
   const char *suffix2[2];
@@ -296,6 +298,7 @@ typedef struct cs_text_result {
   uint64_t written_bp[2];     /* per mate: bases of the records of route 0 (cutadapt's written_bp)              */
   uint32_t n_lines[2];        /* per mate: line ends found in the text (diagnostic for CS_TEXT_ERR_LINE_COUNT)  */
   uint32_t n_long[2];         /* per mate: reads longer than the rows (they took the slow, exact kernel)         */
+  uint64_t text_bytes[3][2];  /* compress = 1: uncompressed size of every stream (route_bytes holds the gzip sizes) */
 } cs_text_result;
 
 typedef struct cs_text cs_text;

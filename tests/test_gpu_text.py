@@ -173,3 +173,38 @@ def test_text_path_errors_are_the_readers_errors():
             # empty batch
             streams3, counts3 = te.run(b"", 0, b"")
             assert counts3 == [0, 0, 0] and streams3 == [[b"", b""]] * 3
+
+
+@pytest.mark.parametrize("n", [1, 40, 3000, 60_000])
+def test_device_compressed_output_is_gzip_of_the_same_text(n):
+    """cs_text_params.compress: every route's output as ONE gzip member written on the device (32 KB deflate blocks with
+    their own Huffman codes, stored blocks where that does not pay: the one-record case) -- any inflater must give
+    back exactly the text the uncompressed form returns, CRC-32 and ISIZE included (Python's gzip checks both)."""
+    import gzip
+    scheme = BUILDIN_ADAPTERS["TAKARAV3"]
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    st.min_length = 60 if n > 100 else 20  # a well-filled "short" route as well
+    tp = util.compile_plan(scheme, st, True)
+    batch = synth.generate_pairs(n, 150, scheme, seed=3, adapter_fraction=0.6)
+    names1 = [s.encode() for s in synth.headers(n, 1)]
+    names2 = [s.encode() for s in synth.headers(n, 2)]
+    text1 = fastq_text(names1, batch.seq1, batch.qual1, batch.len1)
+    text2 = fastq_text(names2, batch.seq2, batch.qual2, batch.len2)
+    plain, counts = run_text(tp, text1, text2, n, batch.stride)
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=2, max_text_bytes=len(text1) + 1024, max_records=n, stride=batch.stride,
+                                 compress=True) as te:
+            for _ in range(2):  # (slot state from the first batch must not leak into the second)
+                packed, counts2 = te.run(text1, n, text2)
+                assert counts2 == counts
+                for route in range(3):
+                    for m in range(2):
+                        if plain[route][m]:
+                            assert packed[route][m][:4] == b"\x1f\x8b\x08\x00"
+                            assert gzip.decompress(packed[route][m]) == plain[route][m], (route, m)
+                        else:
+                            assert packed[route][m] == b""
+    if n >= 3000:
+        ratio = sum(len(x) for row in plain for x in row) / sum(len(x) for row in packed for x in row)
+        assert ratio > 2.5, ratio  # Huffman-only: ~2 bits per base / quality value, headers a little over 4
