@@ -35,8 +35,8 @@ def main():
     def run(tag, inputs, outputs, **env):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update({k: str(v) for k, v in env.items()})
-        for old in work.glob("o[12].fastq"), work.glob("s[12].fastq"), work.glob("gzout_*"):
-            for f in old:  # a run writes NEW files: freeing the previous run's tmpfs pages is not its job
+        for stale in work.glob("o[12].fastq"), work.glob("s[12].fastq"), work.glob("gzout_*"):
+            for f in stale:  # a run writes NEW files: freeing the previous run's tmpfs pages is not its job
                 f.unlink()
         t0 = time.perf_counter()
         try:
