@@ -152,14 +152,25 @@ class GzipSource:
     """Decompressed blocks of a gzip file, in order.  ``blocks()`` yields (buffer, nbytes) pairs: the first
     ``nbytes`` of the uint8 array are text; the consumer hands the array back with ``give`` when done."""
 
-    def __init__(self, path: str, pool=None, take=_np_take, give=_np_give):
+    def __init__(self, path: str, pool=None, take=_np_take, give=_np_give, post=None):
+        """``post(address, nbytes) -> value``: run on every inflated block by the thread that inflated it (the bytes are
+        still in its cache), e.g. a newline count; ``side(buffer)`` hands the value out once."""
         self.path = path
         self.pool = pool
         self.take, self.give = take, give
+        self.post = post
+        self._side = {}
         self.fh = open(path, "rb")
         self.size = self.fh.seek(0, 2)
         self.fh.seek(0)
         self.map = mmap.mmap(self.fh.fileno(), 0, access=mmap.ACCESS_READ) if self.size else None
+
+    def _posted(self, out, produced):
+        if self.post is not None and out is not None:
+            self._side[out.ctypes.data] = self.post(out.ctypes.data, produced)
+
+    def side(self, arr):
+        return self._side.pop(arr.ctypes.data, None)
 
     def close(self):
         if self.map is not None:
@@ -206,14 +217,19 @@ class GzipSource:
         if pos > lo:
             spans.append((lo, pos))
         tail = pos
+        def span(a, b):
+            out, used = _inflate_span(buf, a, b, 4 * (b - a), self.take, self.give)
+            self._posted(out, used)
+            return out, used
+
         if self.pool is None:
             for a, b in spans:
-                yield (a,) + _inflate_span(buf, a, b, 4 * (b - a), self.take, self.give)
+                yield (a,) + span(a, b)
         else:
             from collections import deque
             pending = deque()
             for a, b in spans:
-                pending.append((a, self.pool.submit(_inflate_span, buf, a, b, 4 * (b - a), self.take, self.give)))
+                pending.append((a, self.pool.submit(span, a, b)))
                 if len(pending) >= 8:
                     a0, fut = pending.popleft()
                     yield (a0,) + fut.result()
@@ -242,6 +258,7 @@ class GzipSource:
         if rc != 0:
             self.give(out)
             return rc, 0, None, 0
+        self._posted(out, int(n_out.value))
         return 0, int(n_in.value), out, int(n_out.value)
 
     def _members(self, start: int = 0) -> Iterator[tuple]:
@@ -347,6 +364,7 @@ class GzipSource:
                 raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
             at = pos
             pos += n_in.value
+            self._posted(out, int(n_out.value))
             yield at, out, int(n_out.value)
 
     # -- fallback: zlib streaming, any member size -------------------------------------------------

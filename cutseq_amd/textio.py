@@ -135,6 +135,12 @@ class TextReader(threading.Thread):
         fastq.PINNED.give(buf)
         return bigger
 
+    @staticmethod
+    def _copy_in(dst: int, text: np.ndarray, nbytes: int) -> None:
+        C.memmove(dst, text.ctypes.data, nbytes)
+        if isinstance(text.base, fastq.mmap.mmap):
+            fastq.ARENA.give(text)
+
     def _read_plain(self, fd: int, pos: int, buf: np.ndarray, fill: int, want: int):
         """``want`` bytes of the file from ``pos`` on, several preads (and newline counts) at once in the pool."""
         L = _host()
@@ -173,8 +179,10 @@ class TextReader(threading.Thread):
         fd, pos, gen = -1, self.start_at, None
         skip = self.skip_lines
         left = self.max_records  # records still to hand out (None: everything)
+        copies: List = []  # inflated blocks on their way into `buf` (copied by the pool, awaited before `buf` is read)
         if self.gz:
-            src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give)
+            src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give,
+                                   post=lambda addr, nbytes: int(L.csh_count_newlines(addr, nbytes)))
             gen = src.blocks(self.start_at)
         else:
             fd = os.open(self.path, os.O_RDONLY)
@@ -213,11 +221,15 @@ class TextReader(threading.Thread):
                             eof = True
                             break
                         text, nbytes = item
-                        buf = self._room(buf, fill, nbytes)
-                        C.memmove(buf.ctypes.data + fill, text.ctypes.data, nbytes)
-                        if isinstance(text.base, fastq.mmap.mmap):
-                            fastq.ARENA.give(text)
-                        got = int(L.csh_count_newlines(buf.ctypes.data + fill, nbytes))
+                        if buf.size - fill < nbytes:
+                            for f in copies:
+                                f.result()
+                            copies = []
+                            buf = self._room(buf, fill, nbytes)
+                        got = src.side(text)
+                        if got is None:
+                            got = int(L.csh_count_newlines(text.ctypes.data, nbytes))
+                        copies.append(fastq._pool().submit(self._copy_in, buf.ctypes.data + fill, text, nbytes))
                         marks.append((fill, nbytes, got))
                         fill += nbytes
                         lines += got
@@ -229,6 +241,9 @@ class TextReader(threading.Thread):
                         pos += sum(m[1] for m in more)
                         lines += sum(m[2] for m in more)
                         marks += more
+                for f in copies:
+                    f.result()
+                copies = []
                 if lines >= need:
                     # the block ends right behind newline number `need`: find the piece that holds it, then the byte
                     t0 = time.perf_counter()
@@ -275,6 +290,11 @@ class TextReader(threading.Thread):
                     block.release()
                 return
         finally:
+            for f in copies:
+                try:
+                    f.result()
+                except BaseException:
+                    pass
             if buf is not None:
                 fastq.PINNED.give(buf)
             if gen is not None:
