@@ -179,14 +179,21 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
       }
       for (int i = 1; i <= op.m; ++i)
         if (op.thr[i] != op.thr[i - 1]) out.thr_step[(i - 1) >> 6] |= 1ull << ((i - 1) & 63);
+      out.exists_only = 0;
       out.filter_mode = csdev::FILTER_NONE;
       if (homo && !op.reversed && op.align_flags == CS_WHERE_BACK_NOT_INTERNAL && op.shortcut == CS_SHORTCUT_NONE)
         out.filter_mode = csdev::FILTER_POLY_TAIL;
       else if (homo && !op.reversed && op.align_flags == CS_WHERE_FRONT_NOT_INTERNAL &&
                op.shortcut == CS_SHORTCUT_NONE)
         out.filter_mode = csdev::FILTER_POLY_HEAD;
-      else if (acgt && op.m <= 32)
+      else if (acgt && op.m <= 32) {
         out.filter_mode = csdev::FILTER_MYERS32;
+        // RightmostFrontAdapter (the 5' template-switch artefact) hardly ever matches: existence-only scan
+        // (trim_kernel.hip.inc, myers_none).  CUTSEQ_EXISTS=0 keeps the exact filter for every op.
+        const char *env = getenv("CUTSEQ_EXISTS");
+        if (op.reversed && op.align_flags == CS_WHERE_BACK && op.shortcut == CS_SHORTCUT_NONE && !(env && atoi(env) == 0))
+          out.exists_only = 1;
+      }
       else if (acgt && op.m <= 64 && op.m + op.k <= 127)  // (scores of a column group travel as bytes below 128)
         out.filter_mode = csdev::FILTER_MYERS64;
       break;

@@ -344,7 +344,7 @@ class StreamWriter:
         self.precompressed = precompressed and self.gz
         self.fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
         self.pos = 0
-        self.mappable = True
+        self.mappable = not self.gz  # (gzip members are small: plain pwrite, the pool has better things to do)
         self.q: "queue.Queue" = queue.Queue()
         self.err: Optional[BaseException] = None
         self.t = threading.Thread(target=self._run, daemon=True, name=f"cutseq-write-{os.path.basename(path)}")
