@@ -272,6 +272,7 @@ def main():
             "bytes_per_unit": bytes_per_unit,
         },
         "exact_dp_fraction": round((st1.n_exact_dp + st2.n_exact_dp) / max(1, st1.n_reads + st2.n_reads), 4),
+        "refiltered_fraction": round((st1.n_refiltered + st2.n_refiltered) / max(1, st1.n_reads + st2.n_reads), 4),
     }
     if valu_insts:
         # The bound that governs: VALU issue slots, priced with the clock MEASURED in the same counter passes

@@ -108,7 +108,7 @@ class cs_stats(C.Structure):
         ("n_too_short", C.c_uint64),
         ("n_untrimmed", C.c_uint64),
         ("n_exact_dp", C.c_uint64),
-        ("_reserved", C.c_uint64),
+        ("n_refiltered", C.c_uint64),
         ("op_matched", C.c_uint64 * CS_MAX_OPS),
     ]
 

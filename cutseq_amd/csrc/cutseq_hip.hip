@@ -39,7 +39,7 @@ int fail(int code, const char *fmt, ...) {
 // tile hand-out counters of the scan kernel [2][kTileCounters], then the queue counters (records written
 // per mate, batches claimed per mate), every counter on a 128-byte line of its own
 constexpr size_t kTileCounterDwords = 2 * csdev::kTileCounters * csdev::kTileCounterStride;
-constexpr size_t kTileCounterBytes = (kTileCounterDwords + 4 * csdev::kTileCounterStride) * sizeof(uint32_t);
+constexpr size_t kTileCounterBytes = (kTileCounterDwords + 6 * csdev::kTileCounterStride) * sizeof(uint32_t);
 constexpr size_t kDeferRecordBytes = 32;
 constexpr uint32_t kTileRows = 64;  // one wave per block: no block-level synchronisation at all
 constexpr uint32_t kLdsBudget = 160 * 1024;
@@ -331,6 +331,7 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   a.defer[0] = reinterpret_cast<uint4 *>(ln.d_defer[0]);
   a.defer[1] = reinterpret_cast<uint4 *>(ln.d_defer[1]);
   a.defer_count = ln.d_counters + kTileCounterDwords;
+  a.defer_cap = ln.defer_capacity;
   a.stats = eng->d_stats;
   a.n_reads = n_reads;
   a.stride_dw = stride / 4;
@@ -478,6 +479,14 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
         return rc;
       }
     }
+  // (one existence-only op per mate: its reads share ONE reservation of the queue's top region per tile)
+  for (int m = 0; m < 2; ++m) {
+    bool seen = false;
+    for (int i = 0; i < cnt[m]; ++i) {
+      if (seen) p->host.ops[m][i].exists_only = 0;
+      seen = seen || p->host.ops[m][i].exists_only != 0;
+    }
+  }
   // coded tile: possible when every adapter base is A/C/G/T (always true for cutseq schemes)
   bool coded = true;
   for (int m = 0; m < 2; ++m)

@@ -169,7 +169,7 @@ typedef struct cs_stats {
   uint64_t n_too_short;
   uint64_t n_untrimmed;
   uint64_t n_exact_dp;   /* reads that needed the exact DP (diagnostic)        */
-  uint64_t _reserved;
+  uint64_t n_refiltered; /* reads the existence-only scan of a rare adapter op could not clear (diagnostic)   */
   uint64_t op_matched[CS_MAX_OPS]; /* AdapterCutter.with_adapters per op         */
 } cs_stats;
 

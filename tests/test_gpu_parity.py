@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 def stats_dict(st):
     d = st.as_dict()
     d.pop("n_exact_dp", None)  # diagnostic: the oracle has no notion of the pre-filter
+    d.pop("n_refiltered", None)  # ... nor of the existence-only scan
     return d
 
 
