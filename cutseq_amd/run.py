@@ -488,7 +488,9 @@ def run_cutseq(args, argv=None):
             from . import ranks
             totals = ranks.run_parent(list(sys.argv[1:] if argv is None else argv), args, tp)
     if totals is None:
+        _phase("plan compiled")
         totals = run_pipeline(args, tp)
+        _phase("pipeline done")
     if args.json_file:
         paired = tp.paired
         rep = report.json_report(
@@ -501,7 +503,24 @@ def run_cutseq(args, argv=None):
     return totals
 
 
+def _phase(tag: str) -> None:
+    """Diagnostic (CUTSEQ_PROFILE=1): seconds since the interpreter started, per phase of the run."""
+    if os.environ.get("CUTSEQ_PROFILE") == "1":
+        print(f'{{"cutseq_phase": "{tag}", "process_seconds": {time.perf_counter() - _T_IMPORT + _IMPORT_OFFSET:.3f}}}', file=sys.stderr)
+
+
+_T_IMPORT = time.perf_counter()
+try:  # seconds between process start and this module's import (Linux: from /proc)
+    with open("/proc/self/stat") as _fh:
+        _start_ticks = int(_fh.read().rsplit(")", 1)[1].split()[19])
+    with open("/proc/uptime") as _fh:
+        _IMPORT_OFFSET = float(_fh.read().split()[0]) - _start_ticks / os.sysconf("SC_CLK_TCK")
+except Exception:  # pragma: no cover
+    _IMPORT_OFFSET = 0.0
+
+
 def main(argv: Optional[List[str]] = None):
+    _phase("main")
     parser = build_parser()
     argv = sys.argv[1:] if argv is None else argv
     if len(argv) == 0:

@@ -600,6 +600,9 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         raise
     totals = report.new_totals()
     t_start = time.perf_counter()
+    if PROFILE:
+        from .run import _phase
+        _phase("readers and writers open")
     done: "queue.Queue" = queue.Queue()
     workers = [TextWorker(tp, dev, done, chunk_reads, compress) for dev in devices]
     budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk
