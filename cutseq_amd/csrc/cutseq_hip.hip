@@ -921,6 +921,7 @@ int cs_copy_to_host(int device, void *dst, const void *src, size_t bytes) {
 namespace {
 
 struct TextSlot {
+  uint8_t *d_arena = nullptr;  // the slot's one device allocation
   uint8_t *d_text[2] = {nullptr, nullptr};
   uint32_t *d_nl[2] = {nullptr, nullptr};
   cstext::Rec *d_rec[2] = {nullptr, nullptr};
@@ -976,14 +977,7 @@ void free_text(cs_text *t) {
   if (t->eng) (void)hipSetDevice(t->eng->device);
   for (TextSlot &s : t->slots) {
     if (s.busy && s.formatted) (void)hipEventSynchronize(s.formatted);
-    for (int m = 0; m < 2; ++m)
-      for (void *p : {(void *)s.d_text[m], (void *)s.d_nl[m], (void *)s.d_rec[m], (void *)s.d_idr[m], (void *)s.d_seq[m],
-                      (void *)s.d_qual[m], (void *)s.d_len[m], (void *)s.d_res[m], (void *)s.d_dst[m], (void *)s.d_out[m],
-                      (void *)s.d_lrec[m], (void *)s.d_lres[m], (void *)s.d_long_of[m], (void *)s.d_gzstage[m], (void *)s.d_gz[m],
-                      (void *)s.d_chunk[m], (void *)s.d_chunk_dst[m]})
-        if (p) (void)hipFree(p);
-    for (void *p : {(void *)s.d_cap2, (void *)s.d_blk, (void *)s.d_totals, (void *)s.d_meta})
-      if (p) (void)hipFree(p);
+    if (s.d_arena) (void)hipFree(s.d_arena);  // (every device array of the slot is a piece of it)
     if (s.h_meta) (void)hipHostFree(s.h_meta);
     for (hipEvent_t ev : {s.uploaded, s.formatted, s.fetched})
       if (ev) (void)hipEventDestroy(ev);
@@ -1082,48 +1076,85 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
   const int mates = eng->paired ? 2 : 1;
   const size_t rows = (size_t)max_records * stride;
   for (TextSlot &s : t->slots) {
+    // ONE device allocation per slot, carved up (a hundred separate hipMalloc calls cost a short run more than its
+    // kernels).  The part in front is zeroed -- a batch that is rejected half-way leaves some of those arrays unwritten,
+    // and whatever a later kernel of that batch still reads through them must stay inside the allocations -- the
+    // "not a long read" markers behind it are set to all ones.
+    size_t need = 0;
+    auto reserve = [&](size_t bytes) {
+      const size_t at = need;
+      need += (bytes + 255) & ~(size_t)255;
+      return at;
+    };
+    size_t o_nl[2], o_rec[2], o_idr[2], o_long_of[2], o_text[2], o_seq[2], o_qual[2], o_len[2], o_res[2], o_dst[2], o_out[2],
+        o_lrec[2], o_lres[2], o_gzstage[2] = {0, 0}, o_gz[2] = {0, 0}, o_chunk[2] = {0, 0}, o_chunk_dst[2] = {0, 0};
     for (int m = 0; m < mates; ++m) {
-      TXT_TRY(hipMalloc(&s.d_text[m], max_text_bytes + 64));
-      TXT_TRY(hipMemset(s.d_text[m], 0, max_text_bytes + 64));
-      // (zeroed: a batch that is rejected half-way leaves some of these unwritten, and whatever a later kernel of
-      // that batch still reads through them must stay inside the allocations)
-      TXT_TRY(hipMalloc(&s.d_nl[m], ((size_t)max_records * 4 + 8) * sizeof(uint32_t)));
-      TXT_TRY(hipMemset(s.d_nl[m], 0, ((size_t)max_records * 4 + 8) * sizeof(uint32_t)));
-      TXT_TRY(hipMalloc(&s.d_rec[m], (size_t)max_records * sizeof(cstext::Rec)));
-      TXT_TRY(hipMemset(s.d_rec[m], 0, (size_t)max_records * sizeof(cstext::Rec)));
-      TXT_TRY(hipMalloc(&s.d_idr[m], (size_t)max_records * sizeof(uint32_t)));
-      TXT_TRY(hipMemset(s.d_idr[m], 0, (size_t)max_records * sizeof(uint32_t)));
-      TXT_TRY(hipMalloc(&s.d_seq[m], rows));
-      TXT_TRY(hipMalloc(&s.d_qual[m], rows));
-      TXT_TRY(hipMalloc(&s.d_len[m], (size_t)max_records * sizeof(uint16_t)));
-      TXT_TRY(hipMalloc(&s.d_res[m], (size_t)max_records * sizeof(cs_result)));
-      TXT_TRY(hipMalloc(&s.d_dst[m], (size_t)max_records * sizeof(uint32_t)));
-      TXT_TRY(hipMalloc(&s.d_out[m], out_cap));
-      TXT_TRY(hipMalloc(&s.d_lrec[m], (size_t)max_records * sizeof(cslong::LongRec)));
-      TXT_TRY(hipMalloc(&s.d_lres[m], (size_t)max_records * sizeof(cslong::LongRes)));
-      TXT_TRY(hipMalloc(&s.d_long_of[m], (size_t)max_records * sizeof(uint32_t)));
-      TXT_TRY(hipMemset(s.d_long_of[m], 0xff, (size_t)max_records * sizeof(uint32_t)));
+      o_nl[m] = reserve(((size_t)max_records * 4 + 8) * sizeof(uint32_t));
+      o_rec[m] = reserve((size_t)max_records * sizeof(cstext::Rec));
+      o_idr[m] = reserve((size_t)max_records * sizeof(uint32_t));
+    }
+    const size_t zero_bytes = need;
+    for (int m = 0; m < mates; ++m) o_long_of[m] = reserve((size_t)max_records * sizeof(uint32_t));
+    const size_t ones_bytes = need - zero_bytes;
+    for (int m = 0; m < mates; ++m) {
+      o_text[m] = reserve(max_text_bytes + 64);
+      o_seq[m] = reserve(rows);
+      o_qual[m] = reserve(rows);
+      o_len[m] = reserve((size_t)max_records * sizeof(uint16_t));
+      o_res[m] = reserve((size_t)max_records * sizeof(cs_result));
+      o_dst[m] = reserve((size_t)max_records * sizeof(uint32_t));
+      o_out[m] = reserve(out_cap);
+      o_lrec[m] = reserve((size_t)max_records * sizeof(cslong::LongRec));
+      o_lres[m] = reserve((size_t)max_records * sizeof(cslong::LongRes));
       if (t->compress) {
-        TXT_TRY(hipMalloc(&s.d_gzstage[m], (size_t)t->max_chunks * csdefl::kSlot));
-        TXT_TRY(hipMalloc(&s.d_gz[m], (size_t)t->max_chunks * csdefl::kSlot + 64));
-        TXT_TRY(hipMalloc(&s.d_chunk[m], (size_t)t->max_chunks * sizeof(csdefl::ChunkInfo)));
-        TXT_TRY(hipMalloc(&s.d_chunk_dst[m], (size_t)t->max_chunks * sizeof(uint32_t)));
+        o_gzstage[m] = reserve((size_t)t->max_chunks * csdefl::kSlot);
+        o_gz[m] = reserve((size_t)t->max_chunks * csdefl::kSlot + 64);
+        o_chunk[m] = reserve((size_t)t->max_chunks * sizeof(csdefl::ChunkInfo));
+        o_chunk_dst[m] = reserve((size_t)t->max_chunks * sizeof(uint32_t));
       }
     }
-    if (t->needs_cap2) TXT_TRY(hipMalloc(&s.d_cap2, (size_t)max_records * sizeof(cs_cap2)));
-    const size_t blk = (size_t)2 * (t->seg_blocks + 1) + (size_t)6 * (t->fmt_blocks + 1);
-    TXT_TRY(hipMalloc(&s.d_blk, blk * sizeof(uint32_t)));
-    TXT_TRY(hipMalloc(&s.d_totals, 8 * sizeof(unsigned long long)));
-    TXT_TRY(hipMalloc(&s.d_meta, sizeof(cstext::TextMeta)));
+    const size_t o_cap2 = t->needs_cap2 ? reserve((size_t)max_records * sizeof(cs_cap2)) : 0;
+    const size_t o_blk = reserve(((size_t)2 * (t->seg_blocks + 1) + (size_t)6 * (t->fmt_blocks + 1)) * sizeof(uint32_t));
+    const size_t o_totals = reserve(8 * sizeof(unsigned long long));
+    const size_t o_meta = reserve(sizeof(cstext::TextMeta));
+    TXT_TRY(hipMalloc(&s.d_arena, need));
+    uint8_t *base = s.d_arena;
+    TXT_TRY(hipMemsetAsync(base, 0, zero_bytes, t->h2d));
+    TXT_TRY(hipMemsetAsync(base + zero_bytes, 0xff, ones_bytes, t->h2d));
+    for (int m = 0; m < mates; ++m) {
+      s.d_nl[m] = reinterpret_cast<uint32_t *>(base + o_nl[m]);
+      s.d_rec[m] = reinterpret_cast<cstext::Rec *>(base + o_rec[m]);
+      s.d_idr[m] = reinterpret_cast<uint32_t *>(base + o_idr[m]);
+      s.d_long_of[m] = reinterpret_cast<uint32_t *>(base + o_long_of[m]);
+      s.d_text[m] = base + o_text[m];
+      s.d_seq[m] = base + o_seq[m];
+      s.d_qual[m] = base + o_qual[m];
+      s.d_len[m] = reinterpret_cast<uint16_t *>(base + o_len[m]);
+      s.d_res[m] = reinterpret_cast<cs_result *>(base + o_res[m]);
+      s.d_dst[m] = reinterpret_cast<uint32_t *>(base + o_dst[m]);
+      s.d_out[m] = base + o_out[m];
+      s.d_lrec[m] = reinterpret_cast<cslong::LongRec *>(base + o_lrec[m]);
+      s.d_lres[m] = reinterpret_cast<cslong::LongRes *>(base + o_lres[m]);
+      if (t->compress) {
+        s.d_gzstage[m] = base + o_gzstage[m];
+        s.d_gz[m] = base + o_gz[m];
+        s.d_chunk[m] = reinterpret_cast<csdefl::ChunkInfo *>(base + o_chunk[m]);
+        s.d_chunk_dst[m] = reinterpret_cast<uint32_t *>(base + o_chunk_dst[m]);
+      }
+    }
+    if (t->needs_cap2) s.d_cap2 = reinterpret_cast<cs_cap2 *>(base + o_cap2);
+    s.d_blk = reinterpret_cast<uint32_t *>(base + o_blk);
+    s.d_totals = reinterpret_cast<unsigned long long *>(base + o_totals);
+    s.d_meta = reinterpret_cast<cstext::TextMeta *>(base + o_meta);
     TXT_TRY(hipHostMalloc(&s.h_meta, sizeof(cstext::TextMeta), hipHostMallocPortable));
     TXT_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
     TXT_TRY(hipEventCreateWithFlags(&s.formatted, hipEventDisableTiming));
     TXT_TRY(hipEventCreateWithFlags(&s.fetched, hipEventDisableTiming));
   }
-  // The hipMemset calls above run on the NULL stream and may still be in flight when this returns; the engine's
-  // streams are non-blocking (they do not wait for the NULL stream), so without this a slot's first upload could be
-  // zeroed again under the kernels that read it (seen as a flaky line-count error on a shared GPU).
-  TXT_TRY(hipDeviceSynchronize());
+  // The memsets above must be through before a slot's first upload (same stream: they are) and before a kernel on one
+  // of the engine's other streams reads the arrays (a memset still in flight there was once seen as a flaky
+  // line-count error on a shared GPU): wait for them here.
+  TXT_TRY(hipStreamSynchronize(t->h2d));
 #undef TXT_TRY
   *out = t;
   return CS_OK;

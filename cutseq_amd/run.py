@@ -533,5 +533,24 @@ def main(argv: Optional[List[str]] = None):
         _fail(str(exc))
 
 
+def console_main():
+    """Entry point of the ``cutseq`` console script and of ``python -m cutseq_amd.run``.  When the run is over the
+    process ends at once: unwinding the HIP runtime, its streams and gigabytes of page-locked memory takes longer than
+    a short run itself (tools/startup_probe.py), and the operating system reclaims all of it anyway."""
+    code = 0
+    try:
+        main()
+    except SystemExit as exc:
+        code = exc.code if isinstance(exc.code, int) else (0 if exc.code is None else 1)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        code = 1
+    sys.stdout.flush()
+    sys.stderr.flush()
+    logging.shutdown()
+    os._exit(code)
+
+
 if __name__ == "__main__":
-    main()
+    console_main()

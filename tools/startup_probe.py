@@ -33,7 +33,7 @@ def run(tag, args, extra_env=None, importtime=False):
         if "cutseq_profile" in line or "cutseq_phase" in line:
             print("   ", line[:1400])
     if importtime:
-        rows = [l for l in p.stderr.splitlines() if l.startswith("import time:")]
+        rows = [l for l in p.stderr.splitlines() if l.startswith("import time:") and l.split("|")[1].strip().isdigit()]
         rows.sort(key=lambda l: -int(l.split("|")[1]))
         for l in rows[:8]:
             print("   ", l)
