@@ -14,7 +14,7 @@ from . import abi
 LIB_PATH = Path(__file__).with_name("libcutseq_hip.so")
 
 EXPORTS = (
-    "cs_abi_version", "cs_last_error", "cs_device_count", "cs_plan_create", "cs_plan_destroy", "cs_plan_set_demux",
+    "cs_abi_version", "cs_last_error", "cs_device_count", "cs_plan_create", "cs_plan_destroy", "cs_plan_set_demux", "cs_plan_set_demux_ops",
     "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_device_pipelined", "cs_join", "cs_trim_batch", "cs_sync",
     "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_kernel_time_totals", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
     "cs_free_device", "cs_copy_to_device", "cs_copy_to_host",
@@ -58,6 +58,8 @@ def load() -> C.CDLL:
     L.cs_plan_create.argtypes = [vp, i32, vp, i32, C.POINTER(abi.cs_params), C.POINTER(vp)]
     L.cs_plan_set_demux.restype = i32
     L.cs_plan_set_demux.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    L.cs_plan_set_demux_ops.restype = i32
+    L.cs_plan_set_demux_ops.argtypes = [vp, i32, i32, vp, i32]
     L.cs_plan_destroy.restype = None
     L.cs_plan_destroy.argtypes = [vp]
     L.cs_engine_create.restype = i32

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/cutseq_hip.h"
@@ -73,9 +75,19 @@ constexpr int kLanes = 3;
 
 }  // namespace
 
+// CS_OP_DEMUX with m + k > CS_DEMUX_MAX_PREFIX (cs_plan_set_demux_ops): the barcodes' own PrefixAdapter ops, and a
+// look-up table over the first `depth` bases of the interval that names the barcodes which can still match
+struct DemuxLong {
+  std::vector<csdev::DevOp> ops;
+  std::vector<uint32_t> first;  // per prefix (layout of cs_plan_set_demux): offset into `pool` << 8 | candidates
+  std::vector<uint8_t> pool;    // candidate lists, barcode indices in ascending order
+  int depth = 0;
+};
+
 struct cs_plan {
   csdev::DevPlan host;
   std::vector<uint16_t> demux[2][CS_MAX_OPS];  // look-up tables of the CS_OP_DEMUX ops
+  DemuxLong demux_long[2][CS_MAX_OPS];
 };
 
 #include <mutex>
@@ -206,9 +218,9 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
     case CS_OP_QTRIM:
       break;
     case CS_OP_DEMUX:
-      if (op.m < 1 || op.k > op.m || op.m + op.k > CS_DEMUX_MAX_PREFIX)
+      if (op.m < 1 || op.k > op.m || op.m + op.k > CS_DEMUX_MAX_LONG)
         return fail(CS_ERR_ARG, "mate %d op %d: demux barcode length %u with %u errors (m + k <= %d)", mate, index, op.m,
-                    op.k, CS_DEMUX_MAX_PREFIX);
+                    op.k, CS_DEMUX_MAX_LONG);
       break;
     default:
       return fail(CS_ERR_ARG, "mate %d op %d: unknown op kind %u", mate, index, op.kind);
@@ -535,11 +547,125 @@ int cs_plan_set_demux(cs_plan *plan, int mate, int op_index, const uint16_t *tab
     return fail(CS_ERR_ARG, "mate %d op %d: no such op", mate, op_index);
   const cs_op &op = plan->host.ops[mate - 1][op_index].op;
   if (op.kind != CS_OP_DEMUX) return fail(CS_ERR_ARG, "mate %d op %d is not a CS_OP_DEMUX op", mate, op_index);
+  if (op.m + op.k > CS_DEMUX_MAX_PREFIX)
+    return fail(CS_ERR_ARG, "mate %d op %d: m + k = %d > %d takes cs_plan_set_demux_ops, not a table", mate, op_index,
+                op.m + op.k, CS_DEMUX_MAX_PREFIX);
   size_t want = 0, pw = 1;
   for (int l = 0; l <= op.m + op.k; ++l, pw *= 5) want += pw;
   if (entries != want) return fail(CS_ERR_ARG, "demux table: %zu entries, expected %zu for m + k = %d", entries, want, op.m + op.k);
   try {
     plan->demux[mate - 1][op_index].assign(table, table + entries);
+  } catch (const std::bad_alloc &) {
+    return fail(CS_ERR_NOMEM, "out of memory");
+  }
+  return CS_OK;
+}
+
+namespace {
+
+// Which barcodes can still match a read that starts with a given prefix?  Depth-first over the prefixes (alphabet
+// A, C, T, G, other -- the digits of the table index), one edit-distance column per barcode that is still alive; a
+// barcode is alive while some cell of its column is <= k (Ukkonen: the column minimum never falls again) or its last
+// row was <= k at an earlier column (a match that ends inside the prefix).  k = thr[m] bounds every length's
+// threshold, so the lists are supersets of the barcodes whose PrefixAdapter matches; the device runs those ops
+// themselves on the candidates (trim_kernel.hip.inc, CS_OP_DEMUX).
+struct DemuxWalk {
+  const std::vector<std::string> &digits;  // per barcode: its bases as digits 0..3
+  int m, k, depth;
+  DemuxLong &out;
+  std::vector<size_t> block;  // where the prefixes of each length start
+  bool overflow = false;
+
+  struct Alive {
+    int id;
+    bool done;
+    uint8_t col[CS_MAX_ADAPTER + 1];
+  };
+
+  void emit(size_t at, const std::vector<Alive> &alive) {
+    if (alive.empty()) return;
+    if (out.pool.size() + alive.size() >= (1u << 24) || alive.size() > 255) {
+      overflow = true;
+      return;
+    }
+    out.first[at] = (uint32_t)(out.pool.size() << 8) | (uint32_t)alive.size();
+    for (const Alive &a : alive) out.pool.push_back((uint8_t)a.id);
+  }
+
+  void walk(int len, size_t idx, size_t pw, const std::vector<Alive> &alive) {
+    emit(block[len] + idx, alive);
+    if (len == depth || overflow) return;
+    std::vector<Alive> next;
+    for (int c = 0; c < 5; ++c) {
+      next.clear();
+      for (const Alive &a : alive) {
+        Alive b;
+        b.id = a.id;
+        const std::string &bc = digits[a.id];
+        const int cap = k + 1;  // costs are clamped there: nothing above k is ever told apart
+        int best = b.col[0] = (uint8_t)std::min(len + 1, cap);
+        for (int i = 1; i <= m; ++i) {
+          const int sub = a.col[i - 1] + ((c < 4 && bc[i - 1] == c) ? 0 : 1);
+          const int v = std::min(std::min(sub, std::min(a.col[i] + 1, b.col[i - 1] + 1)), cap);
+          b.col[i] = (uint8_t)v;
+          best = std::min(best, v);
+        }
+        b.done = a.done || b.col[m] <= k;
+        if (b.done || best <= k) next.push_back(b);
+      }
+      if (!next.empty()) walk(len + 1, idx + (size_t)c * pw, pw * 5, next);
+    }
+  }
+};
+
+}  // namespace
+
+int cs_plan_set_demux_ops(cs_plan *plan, int mate, int op_index, const cs_op *ops, int n_ops) {
+  if (!plan || !ops) return fail(CS_ERR_ARG, "null plan or ops");
+  if (mate < 1 || mate > 2 || op_index < 0 || op_index >= plan->host.n_ops[mate - 1])
+    return fail(CS_ERR_ARG, "mate %d op %d: no such op", mate, op_index);
+  const cs_op &op = plan->host.ops[mate - 1][op_index].op;
+  if (op.kind != CS_OP_DEMUX) return fail(CS_ERR_ARG, "mate %d op %d is not a CS_OP_DEMUX op", mate, op_index);
+  if (op.m + op.k <= CS_DEMUX_MAX_PREFIX)
+    return fail(CS_ERR_ARG, "mate %d op %d: m + k = %d <= %d takes a table (cs_plan_set_demux)", mate, op_index,
+                op.m + op.k, CS_DEMUX_MAX_PREFIX);
+  if (n_ops < 1 || n_ops > 255) return fail(CS_ERR_ARG, "between 1 and 255 barcodes");
+  try {
+    DemuxLong dl;
+    std::vector<std::string> digits;
+    for (int b = 0; b < n_ops; ++b) {
+      const cs_op &in = ops[b];
+      if (in.kind != CS_OP_ADAPTER || in.align_flags != CS_WHERE_PREFIX || in.reversed || in.remove != CS_REMOVE_BEFORE ||
+          in.shortcut != CS_SHORTCUT_NONE || in.m != op.m || in.k != op.k || in.min_overlap != in.m)
+        return fail(CS_ERR_ARG, "barcode %d: not the PrefixAdapter op of a %u-base barcode with %u errors", b, op.m, op.k);
+      std::string dg;
+      for (int i = 0; i < in.m; ++i) {
+        if (!is_acgt(in.seq[i])) return fail(CS_ERR_ARG, "barcode %d: bases other than A, C, G, T", b);
+        dg.push_back((char)((in.seq[i] >> 1) & 3));
+      }
+      digits.push_back(dg);
+      csdev::DevOp d;
+      int rc = build_dev_op(in, d, b, mate);
+      if (rc) return rc;
+      if (plan->host.coded)
+        for (int j = 0; j < d.op.m; ++j) d.op.seq[j] = (uint8_t)csdev::base_code(d.op.seq[j]);
+      dl.ops.push_back(d);
+    }
+    dl.depth = std::min((int)op.m + (int)op.k, 9);
+    std::vector<size_t> block(dl.depth + 2, 0);
+    size_t pw = 1;
+    for (int l = 0; l <= dl.depth; ++l, pw *= 5) block[l + 1] = block[l] + pw;
+    dl.first.assign(block[dl.depth + 1], 0u);
+    DemuxWalk w{digits, (int)op.m, (int)op.k, dl.depth, dl, block};
+    std::vector<DemuxWalk::Alive> all(n_ops);
+    for (int b = 0; b < n_ops; ++b) {
+      all[b].id = b;
+      all[b].done = false;
+      for (int i = 0; i <= op.m; ++i) all[b].col[i] = (uint8_t)std::min(i, (int)op.k + 1);
+    }
+    w.walk(0, 0, 1, all);
+    if (w.overflow) return fail(CS_ERR_ARG, "demux: candidate lists exceed the table format");
+    plan->demux_long[mate - 1][op_index] = std::move(dl);
   } catch (const std::bad_alloc &) {
     return fail(CS_ERR_NOMEM, "out of memory");
   }
@@ -609,9 +735,15 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   // DP scratch per wave: 16 survivors x (m+1) cells for the cooperative strips (m <= 32, ACGT),
   // two column slots for everything that falls back to the one-lane-per-survivor DP
   eng->col_dwords = 64;
+  bool has_long_demux = false;
   for (int mt = 0; mt < 2; ++mt)
     for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
       const csdev::DevOp &d = plan->host.ops[mt][i];
+      if (d.op.kind == CS_OP_DEMUX && d.op.m + d.op.k > CS_DEMUX_MAX_PREFIX) {
+        // the resolve kernel runs the barcodes' own ops, one column per lane
+        has_long_demux = true;
+        if (64u * (d.op.m + 1u) > eng->col_dwords) eng->col_dwords = 64u * (d.op.m + 1u);
+      }
       if (d.op.kind != CS_OP_ADAPTER) continue;
       if (d.filter_mode == csdev::FILTER_MYERS64) eng->wide = true;
       const uint32_t need = (d.acgt_only && d.op.m <= 32) ? 16u * (d.op.m + 1u) : 2u * (d.op.m + 1u);
@@ -639,7 +771,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
       if (n > 0 && (lead == 0 || lead == n)) ok = false;  // nothing to split off / nothing left behind the scans
     }
     const char *env = getenv("CUTSEQ_LEAN");
-    eng->lean = ok && env && atoi(env) == 1;
+    eng->lean = ok && env && atoi(env) == 1 && !has_long_demux;
   }
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
@@ -683,6 +815,28 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     for (int mt = 0; mt < 2; ++mt)
       for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
         if (dp.ops[mt][i].op.kind != CS_OP_DEMUX) continue;
+        if (dp.ops[mt][i].op.m + dp.ops[mt][i].op.k > CS_DEMUX_MAX_PREFIX) {
+          // the barcodes' own ops, the table of candidates, the candidate lists: one allocation
+          const DemuxLong &dl = plan->demux_long[mt][i];
+          if (dl.ops.empty()) {
+            fail(CS_ERR_STATE, "mate %d op %d: CS_OP_DEMUX without its barcode ops (cs_plan_set_demux_ops)", mt + 1, i);
+            cs_engine_destroy(eng);
+            return CS_ERR_STATE;
+          }
+          const size_t b_ops = dl.ops.size() * sizeof(csdev::DevOp), b_first = dl.first.size() * sizeof(uint32_t);
+          const size_t o_first = (b_ops + 255) & ~(size_t)255, o_pool = (o_first + b_first + 255) & ~(size_t)255;
+          uint8_t *d = nullptr;
+          ENG_TRY(hipMalloc(&d, o_pool + dl.pool.size() + 256));
+          eng->d_tables.push_back(d);
+          ENG_TRY(hipMemcpy(d, dl.ops.data(), b_ops, hipMemcpyHostToDevice));
+          ENG_TRY(hipMemcpy(d + o_first, dl.first.data(), b_first, hipMemcpyHostToDevice));
+          if (!dl.pool.empty()) ENG_TRY(hipMemcpy(d + o_pool, dl.pool.data(), dl.pool.size(), hipMemcpyHostToDevice));
+          dp.ops[mt][i].peq[0] = (uint64_t)(uintptr_t)(d + o_first);
+          dp.ops[mt][i].peq[1] = (uint64_t)(uintptr_t)(d + o_pool);
+          dp.ops[mt][i].peq[2] = (uint64_t)(uintptr_t)d;
+          dp.ops[mt][i].peq[3] = (uint64_t)dl.depth;
+          continue;
+        }
         const std::vector<uint16_t> &tab = plan->demux[mt][i];
         if (tab.empty()) {
           fail(CS_ERR_STATE, "mate %d op %d: CS_OP_DEMUX without a table (cs_plan_set_demux)", mt + 1, i);

@@ -81,12 +81,14 @@ def ensure_tables(plan: TrimPlan, device: int = 0) -> None:
     """Build the tables the plan's demultiplexing ops still lack (once: engines of several devices share the plan)."""
     with _table_lock:
         for _mate, _i, op in plan.demux_ops():
-            if op.table is None:
+            if op.table is None and op.tabulated:  # (longer barcodes: no table, the device runs their ops)
                 op.table = build_table(op, device, plan.select_rule, plan.indel_tie)
 
 
 def ambiguous_prefixes(op: DemuxOp) -> int:
     """How many full-length prefixes (m + k bases of A/C/G/T only) more than one barcode claims."""
+    if not op.tabulated:
+        raise ValueError("no table of every prefix for barcodes this long")
     span = op.m + op.k
     start = table_entries(span - 1)
     block = op.table[start:]

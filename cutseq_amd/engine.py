@@ -33,7 +33,12 @@ class TrimEngine:
                                          C.cast(a2, C.c_void_p) if a2 is not None else None, n2,
                                          C.byref(params), C.byref(self._plan_h)))
         for mate, index, op in plan.demux_ops():
-            capi.check(self.L.cs_plan_set_demux(self._plan_h, mate, index, op.table.ctypes.data, op.table.size))
+            if op.tabulated:
+                capi.check(self.L.cs_plan_set_demux(self._plan_h, mate, index, op.table.ctypes.data, op.table.size))
+            else:
+                from .plan import pack_ops
+                ops = pack_ops(op.barcode_ops(), limit=255)
+                capi.check(self.L.cs_plan_set_demux_ops(self._plan_h, mate, index, C.cast(ops, C.c_void_p), len(op.barcodes)))
         self.n_slots, self.max_reads, self.max_stride = slots, max_reads, max_stride
         try:
             capi.check(self.L.cs_engine_create(self._plan_h, device, slots, max_reads, max_stride,
@@ -86,7 +91,8 @@ class TrimEngine:
     def submit(self, slot: int, seq1, qual1, len1, seq2=None, qual2=None, len2=None, out=None, bc=None):
         """Asynchronous: returns the (still being filled) result arrays; call ``wait(slot)``.
         ``out``: optional (res1, cap2 | None, res2 | None) arrays to fill (e.g. pinned memory).
-        ``bc``: optional uint8 array [n] for the barcode index of mate 1 (plans with a demultiplexing op)."""
+        ``bc``: optional uint8 array [n] for the barcode index (plans with a demultiplexing op; filled from the mate
+        whose chain holds it)."""
         if seq1.ndim != 2:
             raise ValueError("seq1: expected a 2-D array [n_reads, stride]")
         n, stride = seq1.shape
@@ -104,13 +110,16 @@ class TrimEngine:
             cap2 = np.empty(n, dtype=abi.CAP2_DTYPE) if self.plan.needs_cap2 else None
             out2 = np.empty(n, dtype=abi.RESULT_DTYPE) if seq2 is not None else None
         r1 = self._reads(seq1, qual1, len1, out1, cap2)
-        if bc is not None:
-            if bc.dtype != np.uint8 or bc.shape != (n,) or not bc.flags.c_contiguous:
-                raise ValueError(f"bc: expected a C-contiguous uint8 array of shape ({n},)")
+        if bc is not None and (bc.dtype != np.uint8 or bc.shape != (n,) or not bc.flags.c_contiguous):
+            raise ValueError(f"bc: expected a C-contiguous uint8 array of shape ({n},)")
+        bc_mate = self.plan.demux_mate or 1
+        if bc is not None and bc_mate == 1:
             r1.bc = bc.ctypes.data
         r2p = None
         if seq2 is not None:
             r2 = self._reads(seq2, qual2, len2, out2)
+            if bc is not None and bc_mate == 2:
+                r2.bc = bc.ctypes.data
             r2p = C.byref(r2)
         capi.check(self.L.cs_trim_batch(self._eng_h, slot, C.byref(r1), r2p, n, stride))
         return out1, cap2, out2

@@ -151,8 +151,8 @@ class DemuxOp:
             raise ValueError("duplicate barcode")
         if any(set(b) - set("ACGT") for b in self.barcodes):
             raise ValueError("barcodes must consist of A, C, G, T")
-        if self.m + self.k > abi.CS_DEMUX_MAX_PREFIX:
-            raise ValueError(f"barcode length + allowed errors must not exceed {abi.CS_DEMUX_MAX_PREFIX}")
+        if self.m + self.k > abi.CS_DEMUX_MAX_LONG:
+            raise ValueError(f"barcode length + allowed errors must not exceed {abi.CS_DEMUX_MAX_LONG}")
 
     @property
     def m(self) -> int:
@@ -161,6 +161,16 @@ class DemuxOp:
     @property
     def k(self) -> int:
         return int(self.max_error_rate * self.m)
+
+    @property
+    def tabulated(self) -> bool:
+        """True: the op is a look-up table over every prefix of m + k bases (cs_plan_set_demux); False: longer
+        barcodes, the op carries one PrefixAdapter op per barcode (cs_plan_set_demux_ops)."""
+        return self.m + self.k <= abi.CS_DEMUX_MAX_PREFIX
+
+    def barcode_ops(self):
+        """The barcodes' own adapter ops, as single-barcode plans hold them (cutseq/run.py:357-362, 592-597)."""
+        return [prefix(code, self.max_error_rate, self.match_flag, required=self.required) for code in self.barcodes]
 
     def __repr__(self):
         return (f"Demultiplexer({len(self.barcodes)} x PrefixAdapter(length={self.m}, "
@@ -206,8 +216,13 @@ class TrimPlan:
 
     @property
     def demux(self) -> Optional[DemuxOp]:
-        """The demultiplexing op of mate 1, if the plan has one."""
-        return next((o for o in self.r1.ops if isinstance(o, DemuxOp)), None)
+        """The plan's demultiplexing op, if it has one (mate 1: 5' inline barcode; mate 2: 3' inline barcode)."""
+        return next((o for _m, _i, o in self.demux_ops()), None)
+
+    @property
+    def demux_mate(self) -> int:
+        """1 or 2: the mate whose chain holds the demultiplexing op (0 without one)."""
+        return next((m for m, _i, _o in self.demux_ops()), 0)
 
     def demux_ops(self):
         """(mate, op index, op) of every demultiplexing op."""
@@ -235,13 +250,13 @@ class TrimPlan:
         return a1, len(self.r1.ops), a2, (len(self.r2.ops) if self.r2 is not None else 0)
 
 
-def pack_ops(ops: Sequence[Op]):
-    if len(ops) > abi.CS_MAX_OPS:
-        raise ValueError(f"op chain of {len(ops)} exceeds CS_MAX_OPS={abi.CS_MAX_OPS}")
+def pack_ops(ops: Sequence[Op], limit: int = abi.CS_MAX_OPS):
+    if len(ops) > limit:
+        raise ValueError(f"op chain of {len(ops)} exceeds CS_MAX_OPS={limit}")
     arr = (abi.cs_op * max(1, len(ops)))()
     for i, op in enumerate(ops):
         c = arr[i]
-        c.stat_slot = i
+        c.stat_slot = i % abi.CS_MAX_OPS
         if isinstance(op, AdapterOp):
             c.kind = abi.CS_OP_ADAPTER
             c.align_flags = op.where
@@ -322,16 +337,26 @@ def _poly_t():
     return non_internal_front("T" * POLY_LENGTH, POLY_MAX_ERRORS, abi.CS_F_POLY)
 
 
-def _demux_op(barcode: BarcodeConfig, settings) -> Optional[DemuxOp]:
+def _demux_op(barcode: BarcodeConfig, settings, paired: bool):
+    """-> (op for the 5' inline barcode | None, op for the 3' inline barcode | None): the scheme's 5' inline barcode is
+    the one the barcode list stands for when there is one, else the 3' one -- which starts R2, reverse-complemented
+    (cutseq/run.py:604-608), so that is where its op goes."""
     codes = getattr(settings, "demux_barcodes", None)
     if not codes:
-        return None
-    if barcode.inline5.len == 0:
-        raise ValueError("demultiplexing needs a scheme with a 5' inline barcode, e.g. P5(ATCACG)NNNN>P7")
+        return None, None
+    if barcode.inline5.len == 0 and barcode.inline3.len == 0:
+        raise ValueError("demultiplexing needs a scheme with an inline barcode, e.g. P5(ATCACG)NNNN>P7")
+    at5 = barcode.inline5.len > 0
+    if not at5 and not paired:
+        raise ValueError("demultiplexing on the 3' inline barcode needs paired reads (it is the start of R2)")
+    inline = barcode.inline5 if at5 else barcode.inline3
+    if not at5:
+        from .common import reverse_complement
+        codes = [reverse_complement(c.upper().replace("U", "T")) for c in codes]
     op = DemuxOp(list(codes), MAX_ERRORS, abi.CS_F_INLINE, required=True)
-    if op.m != barcode.inline5.len:
-        raise ValueError(f"the barcodes are {op.m} nt long, the scheme's inline barcode {barcode.inline5.len}")
-    return op
+    if op.m != inline.len:
+        raise ValueError(f"the barcodes are {op.m} nt long, the scheme's inline barcode {inline.len}")
+    return (op, None) if at5 else (None, op)
 
 
 def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_requested: bool = False) -> TrimPlan:
@@ -345,7 +370,7 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     ops.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5, sc))
     ops.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4: inline barcodes
-    demux = _demux_op(barcode, settings)
+    demux, _ = _demux_op(barcode, settings, paired=False)
     if demux is not None:
         untrimmed_filter = True  # a read without any of the barcodes goes where --ensure-inline-barcode sends it
         ops.append(demux)
@@ -415,9 +440,10 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     o1.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     o2.append(back(barcode.p5.rc, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4
-    demux = _demux_op(barcode, settings)
-    if demux is not None:
+    demux, demux3 = _demux_op(barcode, settings, paired=True)
+    if demux is not None or demux3 is not None:
         untrimmed_filter = True
+    if demux is not None:
         o1.append(demux)
         o2.append(CutOp(-barcode.inline5.len))
     elif barcode.inline5.len > 0:
@@ -425,7 +451,8 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
         o2.append(CutOp(-barcode.inline5.len))
     if barcode.inline3.len > 0:
         o1.append(CutOp(-barcode.inline3.len))
-        o2.append(prefix(barcode.inline3.rc, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
+        o2.append(demux3 if demux3 is not None else
+                  prefix(barcode.inline3.rc, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
     # step 5: the mate that starts with the UMI always loses it; the other mate only on read-through
     if barcode.umi5.len > 0:
         o1.append(CutOp(barcode.umi5.len, capture=1))

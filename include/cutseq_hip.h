@@ -58,6 +58,7 @@ enum { CS_OP_ADAPTER = 1, CS_OP_CUT = 2, CS_OP_QTRIM = 3, CS_OP_DEMUX = 4 };
  * 0 .. m + k (reads shorter than m + k) are covered.  The matched barcode's index goes to cs_reads.bc. */
 #define CS_DEMUX_NONE 0xFF      /* cs_reads.bc: no barcode matched                                   */
 #define CS_DEMUX_MAX_PREFIX 11  /* m + k <= 11: at most 5^11 + ... table entries (2 bytes each)       */
+#define CS_DEMUX_MAX_LONG 24    /* m + k <= 24 with cs_plan_set_demux_ops (no table of every prefix)  */
 /* table entry (uint16): [7:0] barcode index or CS_DEMUX_NONE, [11:8] bases the match removes,
  * [14] more than one barcode matched (reported: an exact copy if there is one, else the lowest index) */
 #define CS_DEMUX_ENTRY(id, rstop, ambiguous) ((uint16_t)((id) | ((rstop) << 8) | ((ambiguous) ? 0x4000 : 0)))
@@ -202,6 +203,15 @@ void cs_plan_destroy(cs_plan *plan);
  * m + k, each block indexed by sum(digit[t] * 5^t) with digit = 0, 1, 2, 3 for A, C, T, G (bits 2:1 of the
  * ASCII code) and 4 for anything else; `entries` must be (5^(m+k+1) - 1) / 4.  The plan copies the table. */
 int cs_plan_set_demux(cs_plan *plan, int mate, int op_index, const uint16_t *table, size_t entries);
+
+/* CS_OP_DEMUX with longer barcodes (CS_DEMUX_MAX_PREFIX < m + k <= CS_DEMUX_MAX_LONG; 10- to 20-base barcodes at the
+ * reference's rate of 0.2): a table of every prefix no longer fits, so the op carries the barcodes' own ops instead --
+ * `ops[b]` is the CS_OP_ADAPTER op of barcode b exactly as a single-barcode plan would hold it (CS_WHERE_PREFIX,
+ * CS_REMOVE_BEFORE, min_overlap = m, its thr[] table; A/C/G/T only).  The library derives a look-up table over the
+ * first min(m + k, 9) bases that names the barcodes which can still match (a superset, from plain edit distance), and
+ * the device runs the ops of those candidates on the read and merges the outcomes by the rule of the table entries
+ * above.  Reads of such a plan all pass through the resolve kernel: slower than the table form, same results. */
+int cs_plan_set_demux_ops(cs_plan *plan, int mate, int op_index, const cs_op *ops, int n_ops);
 
 /* One engine per GPU (one per process in the multi-GPU layout; replaces
  * make_runner(inpaths, cores=threads), run.py:436,753). Uploads the op tables, owns a

@@ -93,6 +93,56 @@ def test_plan_create_rejects_bad_tables(lib):
     assert lib.cs_plan_create(C.cast(a1, C.c_void_p), n1, None, 0, C.byref(p), C.byref(h)) == abi.CS_ERR_ARG
 
 
+def test_long_barcodes_take_their_own_ops_not_a_table(lib):
+    """CS_OP_DEMUX with m + k > CS_DEMUX_MAX_PREFIX: cs_plan_set_demux_ops (host side only here: the checks and the
+    candidate table are built without a GPU), and the plan rules around it."""
+    import numpy as np
+    scheme = "ACACGACGCTCTTCCGATCT(ACGTACGTACGT)NNNNNNNN>AGATCGGAAGAGCACACGTC"
+    st = planmod.CutadaptConfig()
+    st.demux_barcodes = ["ACGTACGTACGT", "TTGCAACGGTCA", "GGATCCTTAAGC"]
+    tp = planmod.compile_paired(BarcodeConfig(scheme), st)
+    op = tp.demux
+    assert tp.demux_mate == 1 and not op.tabulated and (op.m, op.k) == (12, 2)
+    rc, h = _create(lib, tp)
+    assert rc == 0, lib.cs_last_error()
+    index = next(i for m, i, _ in tp.demux_ops())
+    ops = planmod.pack_ops(op.barcode_ops(), limit=255)
+    table = np.zeros(10, dtype=np.uint16)
+    assert lib.cs_plan_set_demux(h, 1, index, table.ctypes.data, table.size) == abi.CS_ERR_ARG  # no table this long
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 3) == 0, lib.cs_last_error()
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 0) == abi.CS_ERR_ARG
+    assert lib.cs_plan_set_demux_ops(h, 1, 0, C.cast(ops, C.c_void_p), 3) == abi.CS_ERR_ARG  # op 0 is an adapter op
+    ops[1].seq[3] = ord("N")
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 3) == abi.CS_ERR_ARG
+    ops = planmod.pack_ops(op.barcode_ops(), limit=255)
+    ops[2].align_flags = abi.CS_WHERE_BACK
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 3) == abi.CS_ERR_ARG
+    lib.cs_plan_destroy(h)
+    # a 255-plex of 16-mers: the candidate table is built in well under a second
+    import random, time
+    rng = random.Random(1)
+    codes = sorted({"".join(rng.choice("ACGT") for _ in range(16)) for _ in range(300)})[:255]
+    st.demux_barcodes = codes
+    tp = planmod.compile_paired(BarcodeConfig(scheme.replace("ACGTACGTACGT", codes[0])), st)
+    rc, h = _create(lib, tp)
+    assert rc == 0
+    ops = planmod.pack_ops(tp.demux.barcode_ops(), limit=255)
+    t0 = time.perf_counter()
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 255) == 0, lib.cs_last_error()
+    assert time.perf_counter() - t0 < 5.0
+    lib.cs_plan_destroy(h)
+    # limits and placement
+    st.demux_barcodes = ["A" * 21 + "C", "C" * 21 + "A"]  # m + k = 22 + 4
+    with pytest.raises(ValueError):
+        planmod.compile_paired(BarcodeConfig(scheme.replace("ACGTACGTACGT", "A" * 21 + "C")), st)
+    st.demux_barcodes = ["ACGTACGTAC", "TTGCATGCAA"]
+    only3 = "ACACGACGCTCTTCCGATCTNNNNNNNN>(ACGTACGTAC)AGATCGGAAGAGCACACGTC"
+    tp = planmod.compile_paired(BarcodeConfig(only3), st)
+    assert tp.demux_mate == 2 and tp.demux.barcodes == ["GTACGTACGT", "TTGCATGCAA"]  # as R2 reads them
+    with pytest.raises(ValueError):
+        planmod.compile_single(BarcodeConfig(only3), st)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="GPU present: covered by the gpu suite")
 def test_engine_fails_loudly_without_gpu(lib):
     """No GPU in the build container: the product must raise, never fall back to a CPU path."""

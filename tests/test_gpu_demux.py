@@ -37,9 +37,11 @@ def scheme_with(code: str) -> str:
     return f"ACACGACGCTCTTCCGATCT({code})NNNNNNNN>AGATCGGAAGAGCACACGTC"
 
 
-def plant_barcodes(rng, batch, codes, length):
-    """Overwrite the inline barcode of every R1 with one of `codes` (sometimes damaged, sometimes foreign)."""
+def plant_barcodes(rng, batch, codes, length, mate=1):
+    """Overwrite the inline barcode at the start of every R1 (R2: ``codes`` as that mate reads them) with one of
+    `codes` (sometimes damaged, sometimes foreign)."""
     truth = []
+    seqs, lens = (batch.seq1, batch.len1) if mate == 1 else (batch.seq2, batch.len2)
     for i in range(batch.n):
         u = rng.random()
         if u < 0.08:
@@ -51,16 +53,18 @@ def plant_barcodes(rng, batch, codes, length):
                 code = util.mutate(rng, code, 1)
             elif u < 0.35:
                 code = util.mutate(rng, code, 2)
-        row = batch.seq1[i]
-        tail = bytes(row[length:int(batch.len1[i])])
-        new = (code.encode() + tail)[: int(batch.len1[i])]
+        row = seqs[i]
+        tail = bytes(row[length:int(lens[i])])
+        new = (code.encode() + tail)[: int(lens[i])]
         row[: len(new)] = np.frombuffer(new, dtype=np.uint8)
         truth.append(which)
     return truth
 
 
-@pytest.mark.parametrize("paired,length,count", [(True, 8, 24), (False, 6, 12)])
+@pytest.mark.parametrize("paired,length,count", [(True, 8, 24), (False, 6, 12), (True, 12, 48), (False, 10, 24), (True, 16, 12)])
 def test_demux_equals_independent_runs(paired, length, count):
+    """8- and 6-base barcodes: the table over every prefix of m + k bases; 10, 12 and 16 bases (m + k = 12, 14, 19): no
+    such table fits, the device runs the candidates' own PrefixAdapter ops (cs_plan_set_demux_ops)."""
     rng = random.Random(length * 100 + count)
     codes = barcode_set(rng, count, length, 4)
     st = planmod.CutadaptConfig()
@@ -70,12 +74,13 @@ def test_demux_equals_independent_runs(paired, length, count):
     batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=length, single_end=not paired, art5_fraction=0.01)
     plant_barcodes(rng, batch, codes, length)
     if paired:  # a few very short mates: prefixes shorter than m + k
-        batch.len1[:40] = np.arange(40, dtype=np.uint16) % 12
+        batch.len1[:80] = np.arange(80, dtype=np.uint16) % (length + 4)
     compile_ = planmod.compile_paired if paired else planmod.compile_single
 
     st.demux_barcodes = codes
     tp = compile_(BarcodeConfig(scheme_with(codes[0])), st)
     assert tp.demux is not None and tp.untrimmed_filter
+    assert tp.demux.tabulated == (length <= 9)
     bc = np.empty(n, dtype=np.uint8)
     with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
         res = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
@@ -106,6 +111,51 @@ def test_demux_equals_independent_runs(paired, length, count):
     if paired:
         assert np.array_equal(g2, pick([o2 for _, o2 in runs]))
     assert int(gst1.op_matched[2]) == int((bc != abi.CS_DEMUX_NONE).sum())  # op 2 of mate 1 is the demultiplexer
+
+
+@pytest.mark.parametrize("length,count", [(8, 16), (12, 24)])
+def test_demux_on_the_3prime_barcode_at_the_start_of_r2(length, count):
+    """A scheme whose only inline barcode sits at the 3' end: R2 starts with its reverse complement
+    (cutseq/run.py:604-608), so the demultiplexing op goes into R2's chain and R1 loses the barcode's length where
+    the reference cuts it (run.py:600-603).  Parity: one --ensure-inline-barcode run per barcode."""
+    from cutseq_amd.common import reverse_complement
+
+    def scheme3(code):
+        return f"ACACGACGCTCTTCCGATCTNNNNNNNN>({code})AGATCGGAAGAGCACACGTC"
+
+    rng = random.Random(length + count)
+    codes = barcode_set(rng, count, length, 4)
+    st = planmod.CutadaptConfig()
+    st.ensure_inline_barcode = True
+    n = 5000
+    batch = synth.generate_pairs(n, 150, scheme3(codes[0]), seed=length)
+    plant_barcodes(rng, batch, [reverse_complement(c) for c in codes], length, mate=2)
+    batch.len2[:60] = np.arange(60, dtype=np.uint16) % (length + 4)
+    st.demux_barcodes = codes
+    tp = planmod.compile_paired(BarcodeConfig(scheme3(codes[0])), st)
+    assert tp.demux_mate == 2 and tp.demux.barcodes[0] == reverse_complement(codes[0])
+    bc = np.empty(n, dtype=np.uint8)
+    with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
+        g1, _, g2 = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
+        eng.wait(0)
+    amb = (g2["flags"] & abi.CS_F_AMBIGUOUS) != 0
+    st.demux_barcodes = None
+    runs = []
+    for code in codes:
+        one = planmod.compile_paired(BarcodeConfig(scheme3(code)), st)
+        (o1, _, _), m2 = util.oracle_run(one, batch, threads=8)
+        runs.append((o1, m2[0]))
+    matched = np.stack([(o2["flags"] & abi.CS_F_INLINE) != 0 for _, o2 in runs])
+    assert np.array_equal(matched.sum(axis=0) > 1, amb)
+    want_bc = np.where(matched.any(axis=0), matched.argmax(axis=0), abi.CS_DEMUX_NONE).astype(np.uint8)
+    assert np.array_equal(bc[~amb], want_bc[~amb])
+    assert 0.5 < float((bc != abi.CS_DEMUX_NONE).mean()) < 0.99
+    own = np.where(bc == abi.CS_DEMUX_NONE, 0, bc).astype(np.int64)
+    pick = lambda arrs: np.stack(arrs)[own, np.arange(n)]
+    want2 = pick([o2 for _, o2 in runs])
+    want2["flags"] |= np.where(amb, abi.CS_F_AMBIGUOUS, 0).astype(np.uint8)
+    assert np.array_equal(g2, want2)
+    assert np.array_equal(g1, pick([o1 for o1, _ in runs]))
 
 
 def test_demux_table_matches_the_oracle_on_every_prefix():
