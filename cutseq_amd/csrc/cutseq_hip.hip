@@ -134,6 +134,7 @@ struct cs_engine {
   // split form: the scan kernel stops behind the leading Myers adapter ops, the finish kernel walks the rest
   bool lean = false;
   uint32_t lean_ops[2] = {0, 0};
+  bool long_demux = false;  // a CS_OP_DEMUX op with the barcodes' own ops (cs_plan_set_demux_ops)
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds[2] = {0, 0};
   std::vector<void *> d_tables;           // device copies of the CS_OP_DEMUX tables
@@ -772,6 +773,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     }
     const char *env = getenv("CUTSEQ_LEAN");
     eng->lean = ok && env && atoi(env) == 1 && !has_long_demux;
+    eng->long_demux = has_long_demux;
   }
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
@@ -1152,6 +1154,8 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
   if (!out) return fail(CS_ERR_ARG, "out is null");
   *out = nullptr;
   if (!eng || !params) return fail(CS_ERR_ARG, "null engine or params");
+  if (eng->long_demux)  // (the kernel for reads longer than the rows knows the table form of CS_OP_DEMUX only)
+    return fail(CS_ERR_ARG, "the text path does not take plans that demultiplex barcodes with m + k > %d", CS_DEMUX_MAX_PREFIX);
   if (!n_slots || !max_records || !max_text_bytes) return fail(CS_ERR_ARG, "slots, records and text bytes must be positive");
   if (stride == 0 || stride % 4 || stride > CS_MAX_STRIDE)
     return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);

@@ -5,7 +5,7 @@
 # Outputs land in gpurun_out/round/; copy them to profiles/<round>_* afterwards.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/round
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-copy-probe > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
@@ -16,6 +16,7 @@ bash tools/pmc.sh > $OUT/pmc.log 2>&1 || { echo "pmc failed"; tail -5 $OUT/pmc.l
 mkdir -p profiles && python3 tools/summarize_pmc.py $TAG > $OUT/pmc_summary.log 2>&1 || { echo "summary failed"; cat $OUT/pmc_summary.log; exit 1; }
 cp profiles/${TAG}_pmc_summary.json $OUT/pmc_summary.json
 timeout -k 10 400 python3 bench.py --traffic-json $OUT/pmc_summary.json > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
+timeout -k 10 200 python3 bench.py --serial --cpu-sample 0 > $OUT/bench_serial.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config2 --pairs 10000000 --steps 20 --cpu-sample 1000000 > $OUT/bench_config2.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config4 --cpu-sample 500000 > $OUT/bench_config4.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config5 > $OUT/bench_config5.json 2>> $OUT/bench.err || exit 1
