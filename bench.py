@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: M read-pairs/s of the trimming kernels (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 25 --warmup 2
+    python bench.py --gpus 1 --steps 25 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,9 +12,13 @@ stream, each step's resolve kernel (3 % of the reads, a few latency-bound waves)
 resolve stream under the NEXT step's scan kernel, every step writes its own result arrays, and the timed
 region ends with cs_join + a device synchronize, so all K steps are complete inside it (``--serial``: both
 kernels of a step on one stream, nothing overlaps).  The
-default 25 steps x 4 M pairs = the 100 M-pair workload of BASELINE.json config 3 (TAKARAV3 +
---trim-polyA: UMI + masks + poly-T/A + q-trim).  Reads shard across ranks with no
-collective (weak scaling: every GPU gets its own 4 M-pair batch); torch.distributed is only
+default is 25 steps x 16 M pairs = four times the 100 M-pair workload of BASELINE.json config 3 (TAKARAV3 +
+--trim-polyA: UMI + masks + poly-T/A + q-trim).  Batch size: a launch has a fixed cost of about 0.12 ms (the
+kernel-to-kernel gap and the drain of the last tiles: a wave sees 25 tiles of 57 us each in a 4 M-pair launch), which
+is 8 % of a 4 M-pair step and 2 % of a 16 M-pair step (2764 / 2960 / 3040 M pairs/s at 4 / 8 / 16 M pairs on one
+box, profiles/r03_batch_size.log); 16 M pairs are 9.9 GB of the 288 GB a GPU has.  The default warm-up is ten steps:
+the part needs ~50 ms under load before its clock settles (the first dozen steps run 4 % slower).  Reads shard across
+ranks with no collective (weak scaling: every GPU gets its own 16 M-pair batch); torch.distributed is only
 used for the barrier and the max-over-ranks of the elapsed time.
 
 One JSON line on rank 0, with
@@ -70,8 +74,8 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=4_000_000, help="read pairs per step (resident batch)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--pairs", type=int, default=16_000_000, help="read pairs per step (resident batch)")
     ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")

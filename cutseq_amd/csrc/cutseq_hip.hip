@@ -1440,7 +1440,7 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
         la.gz_route_bytes = &s.d_meta->gz_route_bytes[0][m];
         la.gz_total = &s.d_meta->gz_bytes[m];
         la.gate = da.gate;
-        hipLaunchKernelGGL(csdefl::deflate_layout, dim3(1), dim3(64), 0, rs, la);
+        hipLaunchKernelGGL(csdefl::deflate_layout, dim3(1), dim3(256), 0, rs, la);
         csdefl::CompactArgs ca;
         ca.info = s.d_chunk[m];
         ca.chunk_dst = s.d_chunk_dst[m];

@@ -13,8 +13,22 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from cutseq_amd.build import kernel_source_hash  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+
+
+def pairs_of_the_passes() -> int:
+    """Pairs per launch as the profiled bench runs report it themselves (the JSON line each pass leaves in its log)."""
+    seen = set()
+    for log in glob.glob("gpurun_out/pmc/*.log"):
+        for line in open(log, errors="replace"):
+            if line.startswith("{") and "pairs_per_step_per_gpu" in line:
+                seen.add(int(json.loads(line)["config"]["pairs_per_step_per_gpu"]))
+    if len(seen) != 1:
+        raise SystemExit(f"pairs per launch of the counter passes: {sorted(seen)} (expected exactly one value)")
+    return seen.pop()
+
+
+pairs = int(sys.argv[2]) if len(sys.argv) > 2 else pairs_of_the_passes()
 
 
 def kernel_of(name: str) -> str:
