@@ -333,6 +333,25 @@ class _Shared:
             self._release()
 
 
+_libc = None
+
+
+def _fallocate(fd: int, offset: int, length: int) -> bool:
+    """Linux fallocate(2), mode 0 (extends the file) -> False when the file system has no such thing.  (Not
+    os.posix_fallocate: glibc emulates a missing fallocate by touching every block.)"""
+    global _libc
+    if _libc is None:
+        try:
+            _libc = C.CDLL(None, use_errno=True)
+            _libc.fallocate.restype = C.c_int
+            _libc.fallocate.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64]
+        except (OSError, AttributeError):
+            _libc = False
+    if not _libc:
+        return False
+    return _libc.fallocate(fd, 0, offset, length) == 0
+
+
 class StreamWriter:
     """One output file, written strictly in the order of :meth:`put`.  ``.gz``: the text goes out as gzip members
     of about 4 MB, compressed in the pool (level 1 = cutadapt's default; any split of the text is a valid gzip
@@ -382,7 +401,10 @@ class StreamWriter:
 
     def _copy_mapped(self, mv: memoryview, n: int) -> None:
         start, end = self.pos, self.pos + n
-        os.ftruncate(self.fd, end)
+        # the new range gets its pages in ONE call where the file system can do that (tmpfs, ext4, xfs: 18 GB/s on the
+        # GPU box against 4-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write.py)
+        if not _fallocate(self.fd, start, n):
+            os.ftruncate(self.fd, end)
         base = start - start % _PAGE
         mm = mmap.mmap(self.fd, end - base, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE, offset=base)
         try:
