@@ -47,14 +47,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 HOST_SRC = HERE / "csrc" / "cutseq_host.c"
+HOST_SRCS = (HOST_SRC, HERE / "csrc" / "pinflate.c")
 HOST_OUT = HERE / "libcutseq_host.so"
 
 
 def build_host(force: bool = False) -> Path:
     """Host-only helpers (synthetic generator): plain gcc, no GPU toolchain involved."""
-    if not force and HOST_OUT.exists() and HOST_OUT.stat().st_mtime >= HOST_SRC.stat().st_mtime:
+    if not force and HOST_OUT.exists() and HOST_OUT.stat().st_mtime >= max(p.stat().st_mtime for p in HOST_SRCS):
         return HOST_OUT
-    cmd = ["gcc", "-O3", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-o", str(HOST_OUT), str(HOST_SRC), "-lpthread"]
+    cmd = ["gcc", "-O3", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-o", str(HOST_OUT)] + [str(p) for p in HOST_SRCS] + ["-lpthread"]
     subprocess.run(cmd, check=True)
     return HOST_OUT
 

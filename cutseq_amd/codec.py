@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import mmap
+import os
 import struct
 import threading
 import zlib
@@ -148,6 +149,61 @@ def _inflate_span(buf, lo: int, hi: int, out_hint: int, take=_np_take, give=_np_
     return out, used
 
 
+
+_PI = None
+_PI_LOCK = threading.Lock()
+
+
+def _pinflate():
+    """libcutseq_host.so with the parallel-inflate entry points bound, or None (library not built)."""
+    global _PI
+    if _PI is None:
+        with _PI_LOCK:
+            if _PI is None:
+                try:
+                    from pathlib import Path
+                    L = C.CDLL(str(Path(__file__).with_name("libcutseq_host.so")))
+                    L.csh_deflate_find_block.restype = C.c_int64
+                    L.csh_deflate_find_block.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+                    L.csh_inflate_chunk.restype = C.c_int
+                    L.csh_inflate_chunk.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+                    L.csh_resolve_markers.restype = C.c_int64
+                    L.csh_resolve_markers.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                    L.csh_next_window.restype = C.c_int64
+                    L.csh_next_window.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                    L.csh_crc32_combine_many.restype = C.c_uint32
+                    L.csh_crc32_combine_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+                    _PI = L
+                except (OSError, AttributeError):
+                    _PI = False
+    return _PI or None
+
+
+def _gzip_header_size(buf, pos: int) -> int:
+    """Bytes of the gzip member header at ``pos`` (RFC 1952), 0 if there is none."""
+    n = len(buf)
+    if pos + 18 > n or buf[pos:pos + 3] != b"\x1f\x8b\x08":
+        return 0
+    flg = buf[pos + 3]
+    if flg & 0xE0:
+        return 0
+    p = pos + 10
+    if flg & 4:  # FEXTRA
+        if p + 2 > n:
+            return 0
+        p += 2 + struct.unpack_from("<H", buf, p)[0]
+    for bit in (8, 16):  # FNAME, FCOMMENT: zero-terminated
+        if flg & bit:
+            z = buf.find(b"\0", p)
+            if z < 0:
+                return 0
+            p = z + 1
+    if flg & 2:  # FHCRC
+        p += 2
+    return p - pos if p < n else 0
+
+
 class GzipSource:
     """Decompressed blocks of a gzip file, in order.  ``blocks()`` yields (buffer, nbytes) pairs: the first
     ``nbytes`` of the uint8 array are text; the consumer hands the array back with ``give`` when done."""
@@ -160,6 +216,7 @@ class GzipSource:
         self.take, self.give = take, give
         self.post = post
         self._side = {}
+        self.stats = {}  # diagnostics: chunks of a big member decoded in parallel / again serially
         self.fh = open(path, "rb")
         self.size = self.fh.seek(0, 2)
         self.fh.seek(0)
@@ -240,9 +297,10 @@ class GzipSource:
             yield from self._members(tail)
 
     # -- generic gzip: one libdeflate call per member ----------------------------------------------
-    def _inflate_member_at(self, pos: int, cap: int):
+    def _inflate_member_at(self, pos: int, cap: int, grow: bool = True):
         """One member that starts at ``pos`` -> (rc, bytes consumed, buffer, bytes produced); rc 0 = fine, 3 = does
-        not fit ``_MEMBER_CAP``, anything else = no gzip member starts here (or it is corrupt)."""
+        not fit ``_MEMBER_CAP`` (``grow`` False: does not fit ``cap``), anything else = no gzip member starts here (or
+        it is corrupt)."""
         L, d = libdeflate(), _decompressor()
         base = _view_address(memoryview(self.map))
         n_in, n_out = C.c_size_t(), C.c_size_t()
@@ -250,7 +308,7 @@ class GzipSource:
         while True:
             rc = L.libdeflate_gzip_decompress_ex(d, base + pos, self.size - pos, out.ctypes.data, out.size, C.byref(n_in),
                                                  C.byref(n_out))
-            if rc == 3 and out.size < _MEMBER_CAP:
+            if rc == 3 and grow and out.size < _MEMBER_CAP:
                 self.give(out)
                 out = self.take(_MEMBER_CAP)
                 continue
@@ -278,11 +336,11 @@ class GzipSource:
         tasks = {}  # member start -> future of _inflate_member_at
         cands = []  # ascending candidate starts behind the current member
         scan_from = start + 1
-        cap = [32 << 20]  # output size to start with: the largest member seen so far
+        cap = [min(32 << 20, _MEMBER_CAP)]  # output size to start with: the largest member seen so far
 
         def submit(pos):
             if pos not in tasks:
-                tasks[pos] = self.pool.submit(self._inflate_member_at, pos, cap[0])
+                tasks[pos] = self.pool.submit(self._inflate_member_at, pos, cap[0], False)
 
         running = []  # dropped candidates that had started already: they still read the mapped file
 
@@ -309,11 +367,16 @@ class GzipSource:
                 for p in cands:
                     submit(p)
                 rc, used, out, produced = tasks.pop(head).result()
-                if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
+                if rc == 3 and cap[0] < _MEMBER_CAP and any(head < p <= head + _MEMBER_CAP // 4 for p in cands):
+                    # bigger than the members seen so far, and another member seems to start not far behind it: once
+                    # more with the largest buffer.  (No member magic within 64 MB of compressed bytes: one huge member,
+                    # the usual sequencer output -- not worth inflating a quarter of a gigabyte to find that out.)
+                    cap[0] = _MEMBER_CAP
+                    rc, used, out, produced = self._inflate_member_at(head, _MEMBER_CAP, False)
+                if rc == 3:  # one very large member: its chunks decode in parallel (csrc/pinflate.c), or zlib streams it
                     for p in list(tasks):
                         drop(p)
-                    for arr, nbytes in self._zlib_stream(head):
-                        yield -1, arr, nbytes
+                    yield from self._big_member(head)
                     return
                 if rc != 0:
                     raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
@@ -366,6 +429,145 @@ class GzipSource:
             pos += n_in.value
             self._posted(out, int(n_out.value))
             yield at, out, int(n_out.value)
+
+    # -- one huge member: chunks of the compressed bytes decode side by side (csrc/pinflate.c) ------------------
+    def _big_member(self, head: int) -> Iterator[tuple]:
+        """The member at ``head`` is too large for one libdeflate call.  With a pool: decode it in parallel (and go on
+        with whatever follows it); without one, or without the host library: stream everything from here through zlib."""
+        H = _pinflate() if self.pool is not None else None
+        hdr = _gzip_header_size(self.map, head) if H is not None else 0
+        if H is None or hdr == 0 or os.environ.get("CUTSEQ_PARALLEL_INFLATE", "1") == "0":
+            for arr, nbytes in self._zlib_stream(head):
+                yield -1, arr, nbytes
+            return
+        end = yield from self._parallel_member(H, head + hdr)
+        if end < self.size:
+            yield from self._members(end)
+
+    def _parallel_member(self, H, dstart: int):
+        """Generator over the blocks of the deflate stream that starts at byte ``dstart``; returns the file offset behind
+        the member's trailer.  Chunk i of the compressed bytes is decoded speculatively from the first block boundary the
+        finder sees behind ``i * S`` -- into 16-bit symbols, references into the unknown 32 KB in front written as
+        markers -- and ACCEPTED only if the chain of proven positions arrives at exactly that bit; otherwise the chunk is
+        decoded again from the proven position, serially.  Markers are resolved once the window in front is known."""
+        import numpy as np
+        from collections import deque
+        base = _view_address(memoryview(self.map)) + dstart
+        n = self.size - dstart
+        workers = max(2, getattr(self.pool, "_max_workers", 4))
+        S = max(1 << 20, min(4 << 20, n // (4 * workers)))  # compressed bytes per chunk
+        n_chunks = max(1, (n + S - 1) // S)
+        sym_cap = [8 * S]  # symbols per chunk buffer; grows with the ratio seen
+
+        def decode(start_bit, stop_bit):
+            """-> (rc, end_bit, final, symbols (uint8 array viewed as uint16), n_symbols)"""
+            cap = sym_cap[0]
+            while True:
+                raw = self.take(2 * cap)
+                sym = raw[: 2 * cap].view(np.uint16)
+                eb, no, fin = C.c_int64(), C.c_int64(), C.c_int32()
+                rc = H.csh_inflate_chunk(base, n, start_bit, stop_bit, sym.ctypes.data, cap, C.byref(eb), C.byref(no), C.byref(fin))
+                if rc == -2 and cap < (1 << 30):  # more text than expected in this chunk
+                    self.give(raw)
+                    cap *= 4
+                    sym_cap[0] = max(sym_cap[0], cap)
+                    continue
+                if rc != 0:
+                    self.give(raw)
+                    return rc, 0, 0, None, 0
+                return 0, eb.value, fin.value, raw, no.value
+
+        def speculate(i):
+            lo = i * S * 8
+            start = 0 if i == 0 else H.csh_deflate_find_block(base, n, lo, min(n * 8, lo + 2 * S * 8))
+            if start < 0:
+                return start, (-1, 0, 0, None, 0)
+            return start, decode(start, (i + 1) * S * 8)
+
+        def resolve(raw, n_sym, window):
+            sym = raw[: 2 * n_sym].view(np.uint16)
+            out = self.take(max(n_sym, 1))
+            markers = H.csh_resolve_markers(sym.ctypes.data, n_sym, window.ctypes.data if window is not None else None, out.ctypes.data)
+            self.give(raw)
+            if markers < 0:
+                self.give(out)
+                raise OSError(f"{self.path}: corrupt gzip data (a back-reference in front of the stream's start)")
+            crc = zlib.crc32(memoryview(out)[:n_sym])
+            self._posted(out, n_sym)
+            return out, n_sym, crc
+
+        ahead = 2 * workers
+        spec = {}      # chunk index -> future of speculate
+        resolved = deque()  # futures of resolve, in stream order
+        crcs, lens = [], []
+        pos, window, final, i = 0, None, False, 0
+        next_submit = 0
+        try:
+            while not final:
+                while next_submit < n_chunks and next_submit < i + ahead:
+                    spec[next_submit] = self.pool.submit(speculate, next_submit)
+                    next_submit += 1
+                if i < n_chunks:
+                    start, (rc, end_bit, fin, raw, n_sym) = spec.pop(i).result()
+                else:
+                    start, rc, raw = -1, -1, None
+                self.stats["chunks"] = self.stats.get("chunks", 0) + 1
+                if start != pos or rc != 0:
+                    self.stats["serial"] = self.stats.get("serial", 0) + 1
+                    # not proven (finder missed the boundary, saw a false one, or the chunk overflowed): from the proven
+                    # position, serially
+                    if raw is not None:
+                        self.give(raw)
+                    rc, end_bit, fin, raw, n_sym = decode(pos, (i + 1) * S * 8)
+                    if rc != 0:
+                        raise OSError(f"{self.path}: corrupt gzip data (deflate stream, error {rc})")
+                nxt = np.empty(32768, dtype=np.uint8)
+                sym = raw[: 2 * n_sym].view(np.uint16)
+                if H.csh_next_window(sym.ctypes.data, n_sym, window.ctypes.data if window is not None else None, nxt.ctypes.data) < 0:
+                    raise OSError(f"{self.path}: corrupt gzip data (a back-reference in front of the stream's start)")
+                resolved.append(self.pool.submit(resolve, raw, n_sym, window))
+                window, pos, final = nxt, end_bit, bool(fin)
+                i += 1
+                while resolved and (len(resolved) > ahead or resolved[0].done()):
+                    out, nbytes, crc = resolved.popleft().result()
+                    crcs.append(crc)
+                    lens.append(nbytes)
+                    if nbytes:
+                        yield -1, out, nbytes
+                    else:
+                        self.give(out)
+            while resolved:
+                out, nbytes, crc = resolved.popleft().result()
+                crcs.append(crc)
+                lens.append(nbytes)
+                if nbytes:
+                    yield -1, out, nbytes
+                else:
+                    self.give(out)
+        finally:
+            for fut in spec.values():  # chunks decoded beyond the end of the member (or abandoned on an error)
+                if not fut.cancel():
+                    try:
+                        raw = fut.result()[1][3]
+                        if raw is not None:
+                            self.give(raw)
+                    except Exception:  # noqa: BLE001
+                        pass
+            for fut in resolved:
+                try:
+                    self.give(fut.result()[0])
+                except Exception:  # noqa: BLE001
+                    pass
+        tail = dstart + (pos + 7) // 8
+        if tail + 8 > self.size:
+            raise OSError(f"{self.path}: truncated gzip member (no trailer)")
+        want_crc, want_size = struct.unpack_from("<II", self.map, tail)
+        total = sum(lens)
+        k = len(crcs)
+        crc = int(H.csh_crc32_combine_many((C.c_uint32 * max(k, 1))(*crcs), (C.c_uint32 * max(k, 1))(*lens), k))
+        if crc != want_crc or (total & 0xFFFFFFFF) != want_size:
+            raise OSError(f"{self.path}: corrupt gzip data (CRC-32 / size mismatch)")
+        return tail + 8
 
     # -- fallback: zlib streaming, any member size -------------------------------------------------
     def _zlib_stream(self, start: int) -> Iterator[tuple]:

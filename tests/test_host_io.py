@@ -528,6 +528,75 @@ def test_one_huge_gzip_member_is_streamed_not_reinflated(tmp_path, monkeypatch):
     assert big.size not in fastq.ARENA._free or not any(a is big for a in fastq.ARENA._free[big.size])
 
 
+def test_one_huge_gzip_member_decodes_in_parallel(tmp_path, monkeypatch):
+    """csrc/pinflate.c + codec.GzipSource._parallel_member: the compressed bytes of ONE member are cut into chunks, every
+    chunk is decoded from the block boundary found behind its start (references into the unknown 32 KB in front as
+    markers), accepted only when the chain of proven bit positions arrives exactly there, and resolved afterwards.
+    Same bytes as gzip.decompress for every compressor setting, with members behind the big one, with header fields;
+    buffers all come back; damage is noticed."""
+    import os
+    import random
+    import zlib
+    from cutseq_amd import codec
+    rng = random.Random(9)
+    body = "".join(f"@SIM:{i} 1:N:0:X\n{''.join(rng.choice('ACGT') for _ in range(100))}\n+\n"
+                   f"{''.join(rng.choice('FFFFFF:,#') for _ in range(100))}\n" for i in range(60_000)).encode()  # ~14 MB
+    monkeypatch.setattr(codec, "_MEMBER_CAP", 1 << 20)
+    pool = fastq._pool()
+    live = {}
+
+    def take(n):
+        a = np.empty(n, dtype=np.uint8)
+        live[id(a)] = a
+        return a
+
+    strict = [True]
+
+    def give(a):
+        known = live.pop(id(a), None) is not None
+        assert known or not strict[0], "a buffer was given back twice (or never taken)"
+
+    def read(blob, expect_parallel=True):
+        path = tmp_path / "big.fq.gz"
+        path.write_bytes(blob)
+        src = codec.GzipSource(str(path), pool, take, give)
+        out = bytearray()
+        for arr, n in src.blocks():
+            out += memoryview(arr)[:n]
+            give(arr)
+        stats = dict(src.stats)
+        src.close()
+        assert not live, f"{len(live)} buffers never came back"
+        if expect_parallel:
+            assert stats.get("chunks", 0) >= 3 and stats.get("serial", 0) <= 1, stats
+        return bytes(out)
+
+    for level in (1, 6, 9):
+        assert read(gzip.compress(body, level)) == body
+    for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):  # fixed-code blocks are not what the finder looks for
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
+        assert read(c.compress(body) + c.flush(), expect_parallel=False) == body
+    tail = b"@tail\nACGT\n+\nIIII\n"
+    assert read(gzip.compress(body, 1) + gzip.compress(tail, 6)) == body + tail  # members behind the big one
+    named = b"\x1f\x8b\x08\x08\0\0\0\0\0\xffreads.fq\0" + gzip.compress(body, 1)[10:]
+    assert read(named) == body
+    noise = os.urandom(3 << 20)  # stored blocks only: every chunk is decoded from the proven position, serially
+    assert read(gzip.compress(noise, 1), expect_parallel=False) == noise
+    zeros = bytes(40 << 20)  # ratio 1000: the symbol buffers have to grow
+    assert read(gzip.compress(zeros, 6), expect_parallel=False) == zeros
+    monkeypatch.setenv("CUTSEQ_PARALLEL_INFLATE", "0")  # the zlib stream is still there (its blocks are its own arrays)
+    strict[0] = False
+    assert read(gzip.compress(body, 1), expect_parallel=False) == body
+    strict[0] = True
+    monkeypatch.delenv("CUTSEQ_PARALLEL_INFLATE")
+    for damage in (lambda b: b[:-6] + bytes([b[-6] ^ 0x55]) + b[-5:],          # CRC-32 in the trailer
+                   lambda b: b[:len(b) // 2] + bytes([b[len(b) // 2] ^ 0xFF]) + b[len(b) // 2 + 1:],  # a byte in the middle
+                   lambda b: b[:len(b) // 2]):                                   # truncated
+        with pytest.raises(OSError):
+            read(damage(gzip.compress(body, 1)), expect_parallel=False)
+        live.clear()  # (what an aborted read still holds goes with the garbage collector)
+
+
 def test_barcode_names_must_be_usable_in_file_names(tmp_path):
     from cutseq_amd import demux
     good = tmp_path / "ok.tsv"

@@ -56,6 +56,7 @@ def main():
         dt = time.perf_counter() - t0
         out[tag] = {"seconds": round(dt, 3), "M_pairs_per_s": round(n / dt / 1e6, 3)}
 
+
     plain_in = [str(work / "plain_R1.fastq"), str(work / "plain_R2.fastq")]
     plain_out = ["-o", str(work / "o1.fastq"), str(work / "o2.fastq"), "-s", str(work / "s1.fastq"), str(work / "s2.fastq")]
     run("plain_cold", plain_in, plain_out)
@@ -63,6 +64,24 @@ def main():
     gz_in = [str(work / "syn_R1.fastq.gz"), str(work / "syn_R2.fastq.gz")]
     run("gz_to_gz", gz_in, ["-O", str(work / "gzout")])
     run("gz_to_gz_warm", gz_in, ["-O", str(work / "gzout")])
+    run("plain_to_gz", plain_in, ["-O", str(work / "gzout")])
+    # the usual sequencer output: ONE gzip member per file (gzip -1 of the first quarter of the records), which no
+    # reader can enter in the middle
+    n_single = n // 4
+    t0 = time.perf_counter()
+    procs = []
+    for m in (1, 2):
+        head = subprocess.Popen(["head", "-n", str(4 * n_single), str(work / f"plain_R{m}.fastq")], stdout=subprocess.PIPE)
+        procs.append((head, subprocess.Popen(["gzip", "-1"], stdin=head.stdout, stdout=open(work / f"single_R{m}.fastq.gz", "wb"))))
+    for head, gz in procs:
+        gz.wait()
+        head.wait()
+    out["make_single_member_gz_s"] = round(time.perf_counter() - t0, 2)
+    n_all, n = n, n_single
+    single_in = [str(work / "single_R1.fastq.gz"), str(work / "single_R2.fastq.gz")]
+    run("single_member_gz_to_gz", single_in, ["-O", str(work / "gzout")])
+    out["single_member_gz_to_gz"]["pairs"] = n_single
+    n = n_all
     shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(out))
 
