@@ -76,10 +76,17 @@ static inline uint32_t bits_take(bits_t *b, int k) { /* k <= 32, the buffer hold
   return v;
 }
 
+#define WIDE_BITS 11
 typedef struct {
   uint16_t fast[1 << FAST_BITS]; /* (symbol << 4) | length for codes of up to FAST_BITS bits, 0 otherwise */
   uint16_t count[MAXBITS + 1];
   uint16_t symbol[288];
+  uint8_t len[288];              /* the code lengths the tables were built from */
+  int n;
+  /* literal / length codes only, built by huff_widen for the real decoder: one look-up tells literal, length (with
+   * its base and extra-bit count) and end of block apart.  [3:0] code length (0: longer than WIDE_BITS or no code),
+   * [5:4] 1 literal / 2 length / 3 end of block, [11:8] extra bits, [31:16] literal or length base (0: invalid). */
+  uint32_t wide[1 << WIDE_BITS];
 } huff_t;
 
 /* -> 0 complete code, 1 incomplete, -1 over-subscribed */
@@ -88,6 +95,8 @@ static int huff_build(huff_t *h, const uint8_t *len, int n) {
   memset(h->count, 0, sizeof h->count);
   for (int s = 0; s < n; ++s) h->count[len[s]]++;
   memset(h->fast, 0, sizeof h->fast);
+  memcpy(h->len, len, (size_t)n);
+  h->n = n;
   if (h->count[0] == n) return 1; /* no codes at all */
   int left = 1;
   for (int l = 1; l <= MAXBITS; ++l) {
@@ -118,6 +127,62 @@ static int huff_build(huff_t *h, const uint8_t *len, int n) {
   return left > 0 ? 1 : 0;
 }
 
+static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+
+static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+/* the wide table of a literal / length code (see huff_t) */
+static void huff_widen(huff_t *h) {
+  uint16_t next[MAXBITS + 1];
+  uint32_t code = 0;
+  for (int l = 1; l <= MAXBITS; ++l) {
+    next[l] = (uint16_t)code;
+    code = (code + h->count[l]) << 1;
+  }
+  memset(h->wide, 0, sizeof h->wide);
+  for (int s = 0; s < h->n; ++s) {
+    const int l = h->len[s];
+    if (!l) continue;
+    const uint32_t c = next[l]++;
+    if (l > WIDE_BITS) continue;
+    uint32_t r = 0;
+    for (int i = 0; i < l; ++i) r |= ((c >> i) & 1u) << (l - 1 - i);
+    uint32_t e;
+    if (s < 256)
+      e = ((uint32_t)s << 16) | 0x10u | (uint32_t)l;
+    else if (s == 256)
+      e = 0x30u | (uint32_t)l;
+    else if (s - 257 < 29)
+      e = ((uint32_t)LEN_BASE[s - 257] << 16) | ((uint32_t)LEN_EXTRA[s - 257] << 8) | 0x20u | (uint32_t)l;
+    else
+      e = 0x20u | (uint32_t)l; /* 286, 287: codes without a meaning (base 0) */
+    for (uint32_t i = r; i < (1u << WIDE_BITS); i += 1u << l) h->wide[i] = e;
+  }
+}
+
+/* ... and of a distance code: [3:0] code length, [11:8] extra bits, [31:16] distance base (0: codes 30, 31) */
+static void huff_widen_dist(huff_t *h) {
+  uint16_t next[MAXBITS + 1];
+  uint32_t code = 0;
+  for (int l = 1; l <= MAXBITS; ++l) {
+    next[l] = (uint16_t)code;
+    code = (code + h->count[l]) << 1;
+  }
+  memset(h->wide, 0, sizeof h->wide);
+  for (int s = 0; s < h->n; ++s) {
+    const int l = h->len[s];
+    if (!l) continue;
+    const uint32_t c = next[l]++;
+    if (l > WIDE_BITS) continue;
+    uint32_t r = 0;
+    for (int i = 0; i < l; ++i) r |= ((c >> i) & 1u) << (l - 1 - i);
+    const uint32_t e = s < 30 ? ((uint32_t)DIST_BASE[s] << 16) | ((uint32_t)DIST_EXTRA[s] << 8) | (uint32_t)l : (uint32_t)l;
+    for (uint32_t i = r; i < (1u << WIDE_BITS); i += 1u << l) h->wide[i] = e;
+  }
+}
+
 /* one symbol; -1 = no such code.  The buffer holds at least MAXBITS bits. */
 static inline int huff_decode(bits_t *b, const huff_t *h) {
   const uint16_t e = h->fast[b->buf & ((1u << FAST_BITS) - 1u)];
@@ -145,10 +210,6 @@ static inline int huff_decode(bits_t *b, const huff_t *h) {
   return -1;
 }
 
-static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 static const uint8_t PRE_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 /* the header of a dynamic block (behind its three type bits) -> the two codes; PI_OK or PI_ERR_DATA.
@@ -216,8 +277,10 @@ static void fixed_codes(void) {
   for (; s < 288; ++s) len[s] = 8;
   huff_t l, d;
   huff_build(&l, len, 288);
+  huff_widen(&l);
   for (s = 0; s < 30; ++s) len[s] = 5;
   huff_build(&d, len, 30);
+  huff_widen_dist(&d);
   if (!g_fixed_ready) {
     g_fixed_lit = l;
     g_fixed_dist = d;
@@ -282,6 +345,95 @@ static int coded_block(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_
           const int64_t from = (int64_t)at + j - d;
           out[at + j] = from < 0 ? (uint16_t)(0x8000u | (uint32_t)(WINDOW + from)) : out[from];
         }
+      }
+    }
+    at += (size_t)length;
+  }
+  *o = at;
+  return bits_pos(b) > (uint64_t)b->n * 8u ? PI_ERR_INPUT : PI_OK;
+}
+
+/* The same for the real decoder: the wide table (huff_widen), up to three literals per refill, matches copied in
+ * 16-byte pieces (it wants 280 symbols of room in front of every step: PI_ERR_SPACE earlier than strictly needed). */
+static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_t *out, size_t cap, size_t *o) {
+  size_t at = *o;
+  const uint32_t *lt = lit->wide;
+  const uint32_t mask = (1u << WIDE_BITS) - 1u;
+  for (;;) {
+    if (at + 280 > cap) {  /* three literals + the longest match + the overshoot of its last piece */
+      *o = at;
+      return PI_ERR_SPACE;
+    }
+    bits_refill(b);
+    if (b->pos > b->n + 16) return PI_ERR_INPUT;
+    uint32_t e = lt[b->buf & mask];
+    if ((e & 0x30u) == 0x10u) {
+      b->buf >>= (e & 15u);
+      b->cnt -= (int)(e & 15u);
+      out[at++] = (uint16_t)(e >> 16);
+      e = lt[b->buf & mask];
+      if ((e & 0x30u) == 0x10u) {
+        b->buf >>= (e & 15u);
+        b->cnt -= (int)(e & 15u);
+        out[at++] = (uint16_t)(e >> 16);
+        e = lt[b->buf & mask];
+        if ((e & 0x30u) == 0x10u) {
+          b->buf >>= (e & 15u);
+          b->cnt -= (int)(e & 15u);
+          out[at++] = (uint16_t)(e >> 16);
+          continue;
+        }
+      }
+    }
+    int length;
+    if (e == 0) { /* a code longer than WIDE_BITS (or none): the canonical walk; >= 24 bits are left */
+      int sym = huff_decode(b, lit);
+      if (sym < 0) return PI_ERR_DATA;
+      if (sym < 256) {
+        out[at++] = (uint16_t)sym;
+        continue;
+      }
+      if (sym == 256) break;
+      sym -= 257;
+      if (sym >= 29) return PI_ERR_DATA;
+      bits_refill(b);
+      length = LEN_BASE[sym] + (int)bits_take(b, LEN_EXTRA[sym]);
+    } else {
+      b->buf >>= (e & 15u);
+      b->cnt -= (int)(e & 15u);
+      if ((e & 0x30u) == 0x30u) break; /* end of block */
+      if (b->cnt < 33) bits_refill(b);  /* 5 extra + 15 + 13 for the distance */
+      length = (int)(e >> 16) + (int)bits_take(b, (int)((e >> 8) & 15u));
+      if (length < 3) return PI_ERR_DATA; /* symbols 286 / 287 */
+    }
+    int d;
+    {
+      const uint32_t de = dist->wide[b->buf & mask];
+      if (de & 15u) {
+        b->buf >>= (de & 15u);
+        b->cnt -= (int)(de & 15u);
+        d = (int)(de >> 16);
+        if (d == 0) return PI_ERR_DATA; /* codes 30 / 31 */
+        d += (int)bits_take(b, (int)((de >> 8) & 15u));
+      } else {
+        const int ds = huff_decode(b, dist);
+        if (ds < 0 || ds >= 30) return PI_ERR_DATA;
+        d = DIST_BASE[ds] + (int)bits_take(b, DIST_EXTRA[ds]);
+      }
+    }
+    uint16_t *dst = out + at;
+    if ((size_t)d <= at) {
+      const uint16_t *src = dst - d;
+      if (d >= 8) {
+        for (int j = 0; j < length; j += 8) memcpy(dst + j, src + j, 16);
+      } else {
+        for (int j = 0; j < length; ++j) dst[j] = src[j];
+      }
+    } else {
+      /* reaches in front of the chunk: markers for that part, then the chunk's own symbols */
+      for (int j = 0; j < length; ++j) {
+        const int64_t from = (int64_t)at + j - d;
+        dst[j] = from < 0 ? (uint16_t)(0x8000u | (uint32_t)(WINDOW + from)) : out[from];
       }
     }
     at += (size_t)length;
@@ -385,12 +537,14 @@ int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int
       o += len;
       bits_init(&b, in, n, (at + len) * 8u);
     } else if (type == 1) {
-      rc = coded_block(&b, &g_fixed_lit, &g_fixed_dist, out, (size_t)cap, &o, 0);
+      rc = coded_block_fast(&b, &g_fixed_lit, &g_fixed_dist, out, (size_t)cap, &o);
       if (rc) break;
     } else if (type == 2) {
       rc = dynamic_header(&b, lit, dist);
       if (rc) break;
-      rc = coded_block(&b, lit, dist, out, (size_t)cap, &o, 0);
+      huff_widen(lit);
+      huff_widen_dist(dist);
+      rc = coded_block_fast(&b, lit, dist, out, (size_t)cap, &o);
       if (rc) break;
     } else {
       rc = PI_ERR_DATA;
