@@ -357,75 +357,140 @@ static int coded_block(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_
  * 16-byte pieces (it wants 280 symbols of room in front of every step: PI_ERR_SPACE earlier than strictly needed). */
 static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_t *out, size_t cap, size_t *o) {
   size_t at = *o;
-  const uint32_t *lt = lit->wide;
+  const uint32_t *lt = lit->wide, *dt = dist->wide;
   const uint32_t mask = (1u << WIDE_BITS) - 1u;
+  /* the bit reader's state in locals for the length of the block */
+  const uint8_t *in = b->in;
+  const size_t n = b->n;
+  size_t pos = b->pos;
+  uint64_t buf = b->buf;
+  int cnt = b->cnt;
+  int rc = PI_OK;
+#define PI_REFILL()                              \
+  do {                                           \
+    if (pos + 8 <= n) {                          \
+      uint64_t w_;                               \
+      memcpy(&w_, in + pos, 8);                  \
+      buf |= w_ << cnt;                          \
+      pos += (size_t)((63 - cnt) >> 3);          \
+      cnt |= 56;                                 \
+    } else {                                     \
+      while (cnt <= 56) {                        \
+        buf |= (uint64_t)(pos < n ? in[pos] : 0) << cnt; \
+        pos++;                                   \
+        cnt += 8;                                \
+      }                                          \
+    }                                            \
+  } while (0)
+#define PI_SYNC() (b->pos = pos, b->buf = buf, b->cnt = cnt)
   for (;;) {
-    if (at + 280 > cap) {  /* three literals + the longest match + the overshoot of its last piece */
-      *o = at;
-      return PI_ERR_SPACE;
+    if (at + 280 > cap) {  /* four literals + the longest match + the overshoot of its last piece */
+      rc = PI_ERR_SPACE;
+      break;
     }
-    bits_refill(b);
-    if (b->pos > b->n + 16) return PI_ERR_INPUT;
-    uint32_t e = lt[b->buf & mask];
+    PI_REFILL();
+    if (pos > n + 16) {
+      rc = PI_ERR_INPUT;
+      break;
+    }
+    uint32_t e = lt[buf & mask];
+    /* up to four literals from one refill (4 x 11 bits of >= 56) */
     if ((e & 0x30u) == 0x10u) {
-      b->buf >>= (e & 15u);
-      b->cnt -= (int)(e & 15u);
+      buf >>= (e & 15u);
+      cnt -= (int)(e & 15u);
       out[at++] = (uint16_t)(e >> 16);
-      e = lt[b->buf & mask];
+      e = lt[buf & mask];
       if ((e & 0x30u) == 0x10u) {
-        b->buf >>= (e & 15u);
-        b->cnt -= (int)(e & 15u);
+        buf >>= (e & 15u);
+        cnt -= (int)(e & 15u);
         out[at++] = (uint16_t)(e >> 16);
-        e = lt[b->buf & mask];
+        e = lt[buf & mask];
         if ((e & 0x30u) == 0x10u) {
-          b->buf >>= (e & 15u);
-          b->cnt -= (int)(e & 15u);
+          buf >>= (e & 15u);
+          cnt -= (int)(e & 15u);
           out[at++] = (uint16_t)(e >> 16);
-          continue;
+          e = lt[buf & mask];
+          if ((e & 0x30u) == 0x10u) {
+            buf >>= (e & 15u);
+            cnt -= (int)(e & 15u);
+            out[at++] = (uint16_t)(e >> 16);
+            continue;
+          }
         }
       }
     }
+    /* not a literal; the look-up is still good behind a refill (that only adds bits on top) */
+    PI_REFILL();
     int length;
-    if (e == 0) { /* a code longer than WIDE_BITS (or none): the canonical walk; >= 24 bits are left */
+    if (e == 0) { /* a code longer than WIDE_BITS (or none): the canonical walk */
+      PI_SYNC();
       int sym = huff_decode(b, lit);
-      if (sym < 0) return PI_ERR_DATA;
+      pos = b->pos, buf = b->buf, cnt = b->cnt;
+      if (sym < 0) {
+        rc = PI_ERR_DATA;
+        break;
+      }
       if (sym < 256) {
         out[at++] = (uint16_t)sym;
         continue;
       }
       if (sym == 256) break;
       sym -= 257;
-      if (sym >= 29) return PI_ERR_DATA;
-      bits_refill(b);
-      length = LEN_BASE[sym] + (int)bits_take(b, LEN_EXTRA[sym]);
+      if (sym >= 29) {
+        rc = PI_ERR_DATA;
+        break;
+      }
+      PI_REFILL();
+      length = LEN_BASE[sym] + (int)(buf & ((1u << LEN_EXTRA[sym]) - 1u));
+      buf >>= LEN_EXTRA[sym];
+      cnt -= LEN_EXTRA[sym];
     } else {
-      b->buf >>= (e & 15u);
-      b->cnt -= (int)(e & 15u);
-      if ((e & 0x30u) == 0x30u) break; /* end of block */
-      if (b->cnt < 33) bits_refill(b);  /* 5 extra + 15 + 13 for the distance */
-      length = (int)(e >> 16) + (int)bits_take(b, (int)((e >> 8) & 15u));
-      if (length < 3) return PI_ERR_DATA; /* symbols 286 / 287 */
+      if ((e & 0x30u) == 0x30u) { /* end of block */
+        buf >>= (e & 15u);
+        cnt -= (int)(e & 15u);
+        break;
+      }
+      const uint32_t cl = e & 15u, xb = (e >> 8) & 15u; /* code and extra bits in one step */
+      length = (int)(e >> 16) + (int)((buf >> cl) & ((1u << xb) - 1u));
+      buf >>= cl + xb;
+      cnt -= (int)(cl + xb);
+      if ((e >> 16) == 0) { /* symbols 286 / 287 */
+        rc = PI_ERR_DATA;
+        break;
+      }
     }
+    /* >= 56 - 16 - 5 = 35 bits left: 15 + 13 for the distance */
     int d;
     {
-      const uint32_t de = dist->wide[b->buf & mask];
+      const uint32_t de = dt[buf & mask];
       if (de & 15u) {
-        b->buf >>= (de & 15u);
-        b->cnt -= (int)(de & 15u);
-        d = (int)(de >> 16);
-        if (d == 0) return PI_ERR_DATA; /* codes 30 / 31 */
-        d += (int)bits_take(b, (int)((de >> 8) & 15u));
+        const uint32_t cl = de & 15u, xb = (de >> 8) & 15u;
+        d = (int)(de >> 16) + (int)((buf >> cl) & ((1u << xb) - 1u));
+        buf >>= cl + xb;
+        cnt -= (int)(cl + xb);
+        if ((de >> 16) == 0) { /* codes 30 / 31 */
+          rc = PI_ERR_DATA;
+          break;
+        }
       } else {
+        PI_SYNC();
         const int ds = huff_decode(b, dist);
-        if (ds < 0 || ds >= 30) return PI_ERR_DATA;
-        d = DIST_BASE[ds] + (int)bits_take(b, DIST_EXTRA[ds]);
+        pos = b->pos, buf = b->buf, cnt = b->cnt;
+        if (ds < 0 || ds >= 30) {
+          rc = PI_ERR_DATA;
+          break;
+        }
+        d = DIST_BASE[ds] + (int)(buf & ((1u << DIST_EXTRA[ds]) - 1u));
+        buf >>= DIST_EXTRA[ds];
+        cnt -= DIST_EXTRA[ds];
       }
     }
     uint16_t *dst = out + at;
     if ((size_t)d <= at) {
       const uint16_t *src = dst - d;
       if (d >= 8) {
-        for (int j = 0; j < length; j += 8) memcpy(dst + j, src + j, 16);
+        memcpy(dst, src, 16);
+        for (int j = 8; j < length; j += 8) memcpy(dst + j, src + j, 16);
       } else {
         for (int j = 0; j < length; ++j) dst[j] = src[j];
       }
@@ -438,7 +503,11 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
     }
     at += (size_t)length;
   }
+  PI_SYNC();
+#undef PI_REFILL
+#undef PI_SYNC
   *o = at;
+  if (rc != PI_OK) return rc;
   return bits_pos(b) > (uint64_t)b->n * 8u ? PI_ERR_INPUT : PI_OK;
 }
 
@@ -561,8 +630,8 @@ int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int
 }
 
 /* symbols -> bytes.  `window`: the WINDOW bytes in front of the chunk (marker i stands for window[i]); NULL when
- * nothing can precede the chunk (first chunk of a stream: a marker is corrupt data then).  Returns the number of
- * markers met, -1 for a marker without a window. */
+ * nothing can precede the chunk (first chunk of a stream: a marker is corrupt data then).  Returns >= 0 (a rough count
+ * of markers met, diagnostics only), -1 for a marker without a window. */
 int64_t csh_resolve_markers(const uint16_t *sym, int64_t n, const uint8_t *window, uint8_t *out) {
   int64_t markers = 0;
   if (!window) {
@@ -573,15 +642,32 @@ int64_t csh_resolve_markers(const uint16_t *sym, int64_t n, const uint8_t *windo
     }
     return (any & 0x8000u) ? -1 : 0;
   }
-  for (int64_t i = 0; i < n; ++i) {
-    const uint16_t s = sym[i];
-    if (s & 0x8000u) {
-      out[i] = window[s & 0x7fffu];
-      ++markers;
-    } else {
-      out[i] = (uint8_t)s;
-    }
+  /* one table for both kinds of symbol (a branch per symbol mispredicts half the time when four symbols in five are
+   * markers): bytes stand for themselves, 0x8000 | i for window[i] */
+  uint8_t *lut = (uint8_t *)malloc(65536);
+  if (!lut) return -1;
+  for (int i = 0; i < 256; ++i) lut[i] = (uint8_t)i;
+  memset(lut + 256, 0, 0x8000 - 256);
+  memcpy(lut + 0x8000, window, WINDOW);
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint16_t s0 = sym[i], s1 = sym[i + 1], s2 = sym[i + 2], s3 = sym[i + 3], s4 = sym[i + 4], s5 = sym[i + 5],
+             s6 = sym[i + 6], s7 = sym[i + 7];
+    out[i] = lut[s0];
+    out[i + 1] = lut[s1];
+    out[i + 2] = lut[s2];
+    out[i + 3] = lut[s3];
+    out[i + 4] = lut[s4];
+    out[i + 5] = lut[s5];
+    out[i + 6] = lut[s6];
+    out[i + 7] = lut[s7];
+    markers += ((s0 | s1 | s2 | s3 | s4 | s5 | s6 | s7) >> 15);  /* (a count of 8-symbol groups with markers: diagnostics only) */
   }
+  for (; i < n; ++i) {
+    out[i] = lut[sym[i]];
+    markers += sym[i] >> 15;
+  }
+  free(lut);
   return markers;
 }
 
