@@ -324,7 +324,7 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
     # path below (native parser / formatter in a thread pool) stays for demultiplexing runs and as CUTSEQ_TEXT_PATH=0.
     if tp.demux is None and os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
         from . import textio
-        return textio.run_text_pipeline(args, tp, devices, int(os.environ.get("CUTSEQ_CHUNK_READS", textio.CHUNK_READS)),
+        return textio.run_text_pipeline(args, tp, devices, _block_records(args, len(devices)),
                                         shares=shares)
     if shares is not None:
         raise ValueError("--ranks needs the text path (no demultiplexing, CUTSEQ_TEXT_PATH unset)")
@@ -501,6 +501,27 @@ def run_cutseq(args, argv=None):
         report.write_json(args.json_file, rep)
     print(report.minimal_report(tp, totals), file=sys.stderr)
     return totals
+
+
+def _block_records(args, n_devices: int) -> int:
+    """Records per block of the text path: ``CUTSEQ_CHUNK_READS`` if set, else 262 144 -- less for small inputs, so
+    that a short run does not page-lock and allocate for blocks it never fills (a 2 M-pair run spends more time
+    setting up and tearing down a gigabyte of buffers than trimming): at least a dozen blocks per device."""
+    from . import textio
+    if os.environ.get("CUTSEQ_CHUNK_READS"):
+        return int(os.environ["CUTSEQ_CHUNK_READS"])
+    try:
+        size = os.path.getsize(args.input_file[0])
+    except OSError:
+        return textio.CHUNK_READS
+    if args.input_file[0].endswith(".gz"):
+        size *= 4  # (a guess at the text behind it)
+    records = size // 300  # (a short-read record is ~330 bytes)
+    want = records // (12 * max(n_devices, 1))
+    block = textio.CHUNK_READS
+    while block > 16384 and block > want:
+        block //= 2
+    return block
 
 
 def _phase(tag: str) -> None:

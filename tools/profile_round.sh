@@ -22,4 +22,6 @@ timeout -k 10 200 python3 bench.py --workload config4 --cpu-sample 500000 > $OUT
 timeout -k 10 200 python3 bench.py --workload config5 > $OUT/bench_config5.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 400 python3 tools/tiers.py > $OUT/tiers.json 2> $OUT/tiers.err || { echo "tiers failed"; tail -5 $OUT/tiers.err; exit 1; }
 timeout -k 10 400 python3 tools/e2e_bench.py 8000000 > $OUT/e2e.json 2> $OUT/e2e.err || { echo "e2e failed"; tail -5 $OUT/e2e.err; exit 1; }
+bash tools/text_profile.sh > $OUT/text_profile.log 2>&1 || { echo "text profile failed"; tail -5 $OUT/text_profile.log; exit 1; }
+cp gpurun_out/text/text_plain_kernel_stats.csv gpurun_out/text/text_gz_kernel_stats.csv $OUT/
 cat $OUT/bench.json; head -4 $OUT/kernel_stats.csv | cut -c1-160; cat $OUT/e2e.json
