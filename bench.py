@@ -148,6 +148,12 @@ def main():
     d = {"seq1": up(batch.seq1), "qual1": up(batch.qual1), "len1": up(batch.len1.view(np.int16))}
     if paired:
         d.update(seq2=up(batch.seq2), qual2=up(batch.qual2), len2=up(batch.len2.view(np.int16)))
+    # the host copy is only needed for the CPU legs (baseline sample, parity sample): keep its head, drop ten gigabytes
+    keep = min(n, max(args.cpu_sample, PARITY_SAMPLE))
+    for name in ("seq1", "qual1", "len1", "seq2", "qual2", "len2"):
+        arr = getattr(batch, name, None)
+        if arr is not None:
+            setattr(batch, name, arr[:keep].copy())
     # one set of result arrays per step in flight (the engine lets a call start once the call three before it is done)
     n_sets = 1 if args.serial else 3
     sets = []
