@@ -18,6 +18,7 @@ CS_OP_ADAPTER, CS_OP_CUT, CS_OP_QTRIM, CS_OP_DEMUX = 1, 2, 3, 4
 CS_DEMUX_NONE = 0xFF
 CS_DEMUX_MAX_PREFIX = 11
 CS_DEMUX_MAX_LONG = 24
+CS_DEMUX_BY_OPS = 1
 
 CS_REF_START, CS_QUERY_START, CS_REF_END, CS_QUERY_STOP = 1, 2, 4, 8
 CS_WHERE_BACK = 14

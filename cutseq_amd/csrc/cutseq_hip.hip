@@ -222,6 +222,8 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
       if (op.m < 1 || op.k > op.m || op.m + op.k > CS_DEMUX_MAX_LONG)
         return fail(CS_ERR_ARG, "mate %d op %d: demux barcode length %u with %u errors (m + k <= %d)", mate, index, op.m,
                     op.k, CS_DEMUX_MAX_LONG);
+      // filter_mode of a demultiplexing op: 0 = table look-up, 1 = the barcodes' own ops (cs_plan_set_demux_ops)
+      out.filter_mode = (op.m + op.k > CS_DEMUX_MAX_PREFIX || op.shortcut == CS_DEMUX_BY_OPS) ? 1u : 0u;
       break;
     default:
       return fail(CS_ERR_ARG, "mate %d op %d: unknown op kind %u", mate, index, op.kind);
@@ -548,9 +550,9 @@ int cs_plan_set_demux(cs_plan *plan, int mate, int op_index, const uint16_t *tab
     return fail(CS_ERR_ARG, "mate %d op %d: no such op", mate, op_index);
   const cs_op &op = plan->host.ops[mate - 1][op_index].op;
   if (op.kind != CS_OP_DEMUX) return fail(CS_ERR_ARG, "mate %d op %d is not a CS_OP_DEMUX op", mate, op_index);
-  if (op.m + op.k > CS_DEMUX_MAX_PREFIX)
-    return fail(CS_ERR_ARG, "mate %d op %d: m + k = %d > %d takes cs_plan_set_demux_ops, not a table", mate, op_index,
-                op.m + op.k, CS_DEMUX_MAX_PREFIX);
+  if (plan->host.ops[mate - 1][op_index].filter_mode)
+    return fail(CS_ERR_ARG, "mate %d op %d: m + k = %d > %d (or CS_DEMUX_BY_OPS) takes cs_plan_set_demux_ops, not a table", mate,
+                op_index, op.m + op.k, CS_DEMUX_MAX_PREFIX);
   size_t want = 0, pw = 1;
   for (int l = 0; l <= op.m + op.k; ++l, pw *= 5) want += pw;
   if (entries != want) return fail(CS_ERR_ARG, "demux table: %zu entries, expected %zu for m + k = %d", entries, want, op.m + op.k);
@@ -627,9 +629,9 @@ int cs_plan_set_demux_ops(cs_plan *plan, int mate, int op_index, const cs_op *op
     return fail(CS_ERR_ARG, "mate %d op %d: no such op", mate, op_index);
   const cs_op &op = plan->host.ops[mate - 1][op_index].op;
   if (op.kind != CS_OP_DEMUX) return fail(CS_ERR_ARG, "mate %d op %d is not a CS_OP_DEMUX op", mate, op_index);
-  if (op.m + op.k <= CS_DEMUX_MAX_PREFIX)
-    return fail(CS_ERR_ARG, "mate %d op %d: m + k = %d <= %d takes a table (cs_plan_set_demux)", mate, op_index,
-                op.m + op.k, CS_DEMUX_MAX_PREFIX);
+  if (!plan->host.ops[mate - 1][op_index].filter_mode)
+    return fail(CS_ERR_ARG, "mate %d op %d: m + k = %d <= %d takes a table (cs_plan_set_demux) unless the op says CS_DEMUX_BY_OPS",
+                mate, op_index, op.m + op.k, CS_DEMUX_MAX_PREFIX);
   if (n_ops < 1 || n_ops > 255) return fail(CS_ERR_ARG, "between 1 and 255 barcodes");
   try {
     DemuxLong dl;
@@ -740,7 +742,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   for (int mt = 0; mt < 2; ++mt)
     for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
       const csdev::DevOp &d = plan->host.ops[mt][i];
-      if (d.op.kind == CS_OP_DEMUX && d.op.m + d.op.k > CS_DEMUX_MAX_PREFIX) {
+      if (d.op.kind == CS_OP_DEMUX && d.filter_mode) {
         // the resolve kernel runs the barcodes' own ops, one column per lane
         has_long_demux = true;
         if (64u * (d.op.m + 1u) > eng->col_dwords) eng->col_dwords = 64u * (d.op.m + 1u);
@@ -817,7 +819,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     for (int mt = 0; mt < 2; ++mt)
       for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
         if (dp.ops[mt][i].op.kind != CS_OP_DEMUX) continue;
-        if (dp.ops[mt][i].op.m + dp.ops[mt][i].op.k > CS_DEMUX_MAX_PREFIX) {
+        if (dp.ops[mt][i].filter_mode) {
           // the barcodes' own ops, the table of candidates, the candidate lists: one allocation
           const DemuxLong &dl = plan->demux_long[mt][i];
           if (dl.ops.empty()) {

@@ -5,8 +5,9 @@ The op stands for one ``AdapterCutter([PrefixAdapter(barcode, rate)])`` per barc
 adapter matches, and how many bases it removes, depends on nothing but the first ``m + k`` bases of the
 read (``Aligner.locate`` stops at column ``m + k`` without a free query start).  So the table is built by
 RUNNING those adapter ops -- the device's own, through the C ABI -- on every possible prefix of every
-length 0 .. m + k over the alphabet {A, C, T, G, other}, one single-op plan per barcode, and merging the
-outcomes: "equal to B independent ``--ensure-inline-barcode`` runs" holds by construction.
+length 0 .. m + k over the alphabet {A, C, T, G, other} and merging the outcomes (an exact copy of a barcode
+first, else the lowest index; more than one claimant is flagged): "equal to B independent
+``--ensure-inline-barcode`` runs" holds by construction.
 """
 from __future__ import annotations
 
@@ -15,7 +16,7 @@ import threading
 import numpy as np
 
 from . import abi
-from .plan import DemuxOp, MateChain, TrimPlan, prefix
+from .plan import DemuxOp, MateChain, TrimPlan
 
 DIGITS = b"ACTGN"  # digit d of the base-5 index = bits 2:1 of the ASCII code for A, C, T, G; 4 = anything else
 
@@ -45,36 +46,29 @@ def all_prefixes(span: int):
 
 def build_table(op: DemuxOp, device: int = 0, select_rule: int = abi.CS_SELECT_LEFTMOST,
                 indel_tie: int = abi.CS_TIE_INSERTION) -> np.ndarray:
-    """The table of ``op`` (uint16, ``table_entries(m + k)`` entries), computed on ``device``."""
+    """The table of ``op`` (uint16, ``table_entries(m + k)`` entries), computed on ``device``: ONE pass of the op's
+    other form -- the barcodes' own PrefixAdapter ops on every candidate, merged on the device (CS_DEMUX_BY_OPS,
+    ``cs_plan_set_demux_ops``) -- over every possible prefix.  (Until round 3 this ran one single-barcode engine per
+    barcode and merged in numpy: five seconds for a 96-plex, most of a short run.)"""
     from .engine import TrimEngine
 
     span = op.m + op.k
     seq, lens = all_prefixes(span)
     qual = np.full_like(seq, ord("I"))
     n = len(lens)
-    best = np.full(n, abi.CS_DEMUX_NONE, dtype=np.uint16)
-    rstop = np.zeros(n, dtype=np.uint16)
-    hits = np.zeros(n, dtype=np.uint16)
-    exact_taken = np.zeros(n, dtype=bool)
-    for index, code in enumerate(op.barcodes):
-        one = TrimPlan(r1=MateChain([prefix(code, op.max_error_rate, abi.CS_F_INLINE)]), r2=None, has_umi=False,
-                       min_length=0, untrimmed_filter=False, select_rule=select_rule, indel_tie=indel_tie)
-        with TrimEngine(one, device=device, slots=1, max_reads=n, max_stride=seq.shape[1]) as eng:
-            res, _, _ = eng.trim(seq, qual, lens)
-        matched = (res["flags"] & abi.CS_F_INLINE) != 0
-        # an exact copy of the barcode at the start beats an inexact match of another one; else the lowest index
-        m = op.m
-        exact = matched & (lens >= m) & (res["start"] == m) & (seq[:, :m] == np.frombuffer(code.encode(), np.uint8)).all(axis=1)
-        take = matched & ((best == abi.CS_DEMUX_NONE) | (exact & ~exact_taken))
-        best[take] = index
-        rstop[take] = res["start"][take]
-        exact_taken |= exact
-        hits += matched
-    table = best | (rstop << 8) | ((hits > 1).astype(np.uint16) << 14)
+    probe = DemuxOp(list(op.barcodes), op.max_error_rate, abi.CS_F_INLINE, required=False, by_ops=True)
+    one = TrimPlan(r1=MateChain([probe]), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                   select_rule=select_rule, indel_tie=indel_tie)
+    bc = np.empty(n, dtype=np.uint8)
+    with TrimEngine(one, device=device, slots=1, max_reads=n, max_stride=seq.shape[1]) as eng:
+        res, _, _ = eng.submit(0, seq, qual, lens, bc=bc)
+        eng.wait(0)
+    ambiguous = ((res["flags"] & abi.CS_F_AMBIGUOUS) != 0).astype(np.uint16)
+    table = bc.astype(np.uint16) | (res["start"].astype(np.uint16) << 8) | (ambiguous << 14)
     return np.ascontiguousarray(table, dtype=np.uint16)
 
 
-_table_lock = threading.Lock()
+_table_lock = threading.RLock()  # (re-entrant: building a table runs an engine of its own)
 
 
 def ensure_tables(plan: TrimPlan, device: int = 0) -> None:

@@ -24,7 +24,7 @@ class TrimEngine:
         self.device = device
         self._plan_h = C.c_void_p()
         self._eng_h = C.c_void_p()
-        if any(True for _ in plan.demux_ops()):
+        if any(op.tabulated and op.table is None for _m, _i, op in plan.demux_ops()):
             from . import demux  # tables of the demultiplexing ops: built on this device when still missing
             demux.ensure_tables(plan, device)
         a1, n1, a2, n2 = plan.pack()

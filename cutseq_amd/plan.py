@@ -140,6 +140,7 @@ class DemuxOp:
     match_flag: int = 0
     required: bool = True
     table: Optional[object] = None  # numpy uint16 array once built
+    by_ops: bool = False  # the barcodes' own ops even where a table would fit (how the tables themselves are built)
 
     def __post_init__(self):
         self.barcodes = [b.upper().replace("U", "T") for b in self.barcodes]
@@ -166,7 +167,7 @@ class DemuxOp:
     def tabulated(self) -> bool:
         """True: the op is a look-up table over every prefix of m + k bases (cs_plan_set_demux); False: longer
         barcodes, the op carries one PrefixAdapter op per barcode (cs_plan_set_demux_ops)."""
-        return self.m + self.k <= abi.CS_DEMUX_MAX_PREFIX
+        return self.m + self.k <= abi.CS_DEMUX_MAX_PREFIX and not self.by_ops
 
     def barcode_ops(self):
         """The barcodes' own adapter ops, as single-barcode plans hold them (cutseq/run.py:357-362, 592-597)."""
@@ -283,6 +284,7 @@ def pack_ops(ops: Sequence[Op], limit: int = abi.CS_MAX_OPS):
             c.capture = op.capture
         elif isinstance(op, DemuxOp):
             c.kind = abi.CS_OP_DEMUX
+            c.shortcut = abi.CS_DEMUX_BY_OPS if op.by_ops else 0
             c.m, c.k = op.m, op.k
             c.match_flag = op.match_flag
             c.required = 1 if op.required else 0

@@ -59,6 +59,8 @@ enum { CS_OP_ADAPTER = 1, CS_OP_CUT = 2, CS_OP_QTRIM = 3, CS_OP_DEMUX = 4 };
 #define CS_DEMUX_NONE 0xFF      /* cs_reads.bc: no barcode matched                                   */
 #define CS_DEMUX_MAX_PREFIX 11  /* m + k <= 11: at most 5^11 + ... table entries (2 bytes each)       */
 #define CS_DEMUX_MAX_LONG 24    /* m + k <= 24 with cs_plan_set_demux_ops (no table of every prefix)  */
+#define CS_DEMUX_BY_OPS 1       /* cs_op.shortcut of a CS_OP_DEMUX op: take cs_plan_set_demux_ops whatever m + k is
+                                   (how cutseq_amd/demux.py builds the TABLES: one pass over every prefix)  */
 /* table entry (uint16): [7:0] barcode index or CS_DEMUX_NONE, [11:8] bases the match removes,
  * [14] more than one barcode matched (reported: an exact copy if there is one, else the lowest index) */
 #define CS_DEMUX_ENTRY(id, rstop, ambiguous) ((uint16_t)((id) | ((rstop) << 8) | ((ambiguous) ? 0x4000 : 0)))
@@ -115,7 +117,7 @@ typedef struct cs_op {
   uint8_t reversed;      /* ADAPTER: 1 = RightmostFrontAdapter: `seq` holds the reversed
                             adapter, the aligner walks the read right-to-left        */
   uint8_t remove;        /* ADAPTER: CS_REMOVE_BEFORE (read[rstop:]) / _AFTER (read[:rstart]) */
-  uint8_t shortcut;      /* ADAPTER: CS_SHORTCUT_*                                    */
+  uint8_t shortcut;      /* ADAPTER: CS_SHORTCUT_*; DEMUX: CS_DEMUX_BY_OPS = the barcodes' own ops even where a table would fit */
   uint8_t match_flag;    /* ADAPTER: CS_F_* bit OR-ed into the result when it matched */
   uint8_t required;      /* ADAPTER: listed in IsUntrimmedAny -> CS_F_UNTRIMMED if it did not match */
   uint8_t conditional;   /* CUT: ConditionalCutter semantics (run.py:145-161)         */
@@ -206,6 +208,7 @@ int cs_plan_set_demux(cs_plan *plan, int mate, int op_index, const uint16_t *tab
 
 /* CS_OP_DEMUX with longer barcodes (CS_DEMUX_MAX_PREFIX < m + k <= CS_DEMUX_MAX_LONG; 10- to 20-base barcodes at the
  * reference's rate of 0.2): a table of every prefix no longer fits, so the op carries the barcodes' own ops instead --
+ * (also for shorter ones when the op says CS_DEMUX_BY_OPS)
  * `ops[b]` is the CS_OP_ADAPTER op of barcode b exactly as a single-barcode plan would hold it (CS_WHERE_PREFIX,
  * CS_REMOVE_BEFORE, min_overlap = m, its thr[] table; A/C/G/T only).  The library derives a look-up table over the
  * first min(m + k, 9) bases that names the barcodes which can still match (a superset, from plain edit distance), and
