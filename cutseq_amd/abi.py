@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-CS_ABI_VERSION = 4
+CS_ABI_VERSION = 5
 CS_MAX_ADAPTER = 128
 CS_MAX_OPS = 24
 CS_MAX_STRIDE = 1536
@@ -143,6 +143,8 @@ class cs_text_params(C.Structure):
         ("max_tag", C.c_uint32),
         ("suffix1", C.c_char_p * 2),
         ("suffix2", C.c_char_p * 2),
+        ("n_bins", C.c_uint32),
+        ("_reserved", C.c_uint32),
     ]
 
 
@@ -163,7 +165,7 @@ class cs_text_result(C.Structure):
     ]
 
 
-assert C.sizeof(cs_text_params) == 40 and C.sizeof(cs_text_result) == 176
+assert C.sizeof(cs_text_params) == 48 and C.sizeof(cs_text_result) == 176
 assert C.sizeof(cs_op) == 284, C.sizeof(cs_op)
 assert C.sizeof(cs_result) == 8
 assert C.sizeof(cs_cap2) == 4

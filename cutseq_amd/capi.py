@@ -18,7 +18,7 @@ EXPORTS = (
     "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_device_pipelined", "cs_join", "cs_trim_batch", "cs_sync",
     "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_kernel_time_totals", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
     "cs_free_device", "cs_copy_to_device", "cs_copy_to_host",
-    "cs_text_create", "cs_text_destroy", "cs_text_submit", "cs_text_wait", "cs_text_fetch",
+    "cs_text_create", "cs_text_destroy", "cs_text_submit", "cs_text_wait", "cs_text_routes", "cs_text_fetch",
 )
 
 
@@ -105,6 +105,8 @@ def load() -> C.CDLL:
     L.cs_text_submit.argtypes = [vp, u32, vp, u64, vp, u64, u32]
     L.cs_text_wait.restype = i32
     L.cs_text_wait.argtypes = [vp, u32, C.POINTER(abi.cs_text_result)]
+    L.cs_text_routes.restype = i32
+    L.cs_text_routes.argtypes = [vp, u32, vp, vp, vp]
     L.cs_text_fetch.restype = i32
     L.cs_text_fetch.argtypes = [vp, u32, vp, vp]
     if L.cs_abi_version() != abi.CS_ABI_VERSION:

@@ -135,6 +135,8 @@ struct cs_engine {
   bool lean = false;
   uint32_t lean_ops[2] = {0, 0};
   bool long_demux = false;  // a CS_OP_DEMUX op with the barcodes' own ops (cs_plan_set_demux_ops)
+  int demux_mate = -1;      // 0 / 1: the mate whose chain holds a CS_OP_DEMUX op
+  uint32_t demux_bins = 0;  // ... and how many barcodes its table names
   std::vector<Slot> slots;
   uint32_t max_dynamic_lds[2] = {0, 0};
   std::vector<void *> d_tables;           // device copies of the CS_OP_DEMUX tables
@@ -742,6 +744,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
   for (int mt = 0; mt < 2; ++mt)
     for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
       const csdev::DevOp &d = plan->host.ops[mt][i];
+      if (d.op.kind == CS_OP_DEMUX) eng->demux_mate = mt;
       if (d.op.kind == CS_OP_DEMUX && d.filter_mode) {
         // the resolve kernel runs the barcodes' own ops, one column per lane
         has_long_demux = true;
@@ -1078,6 +1081,13 @@ int cs_copy_to_host(int device, void *dst, const void *src, size_t bytes) {
 
 namespace {
 
+struct RouteBlock {  // demultiplexing plans: per route what TextMeta holds for the three ordinary routes
+  unsigned long long bytes[cstext::kMaxRoutes][2];
+  unsigned long long gz_bytes[cstext::kMaxRoutes][2];
+  uint32_t count[cstext::kMaxRoutes];
+  uint32_t _pad[2];
+};
+
 struct TextSlot {
   uint8_t *d_arena = nullptr;  // the slot's one device allocation
   uint8_t *d_text[2] = {nullptr, nullptr};
@@ -1101,6 +1111,8 @@ struct TextSlot {
   unsigned long long *d_totals = nullptr;  // [2] line totals, [6] format column sums
   cstext::TextMeta *d_meta = nullptr;
   cstext::TextMeta *h_meta = nullptr;      // pinned
+  uint8_t *d_bc = nullptr;                 // demultiplexing plans: barcode index per record
+  RouteBlock *d_routes = nullptr, *h_routes = nullptr;  // ... and the sizes of their 3 + n_bins route streams
   hipEvent_t uploaded = nullptr, formatted = nullptr, fetched = nullptr;
   uint32_t n = 0;
   bool busy = false, waited = false;
@@ -1117,6 +1129,7 @@ struct cs_text {
   bool needs_cap2 = false;
   bool compress = false;      // the output streams leave the device as gzip members
   uint32_t max_chunks = 0;
+  uint32_t n_routes = 3;      // 3 + cs_text_params.n_bins
   hipStream_t h2d = nullptr, d2h = nullptr;
   std::vector<TextSlot> slots;
 };
@@ -1137,6 +1150,7 @@ void free_text(cs_text *t) {
     if (s.busy && s.formatted) (void)hipEventSynchronize(s.formatted);
     if (s.d_arena) (void)hipFree(s.d_arena);  // (every device array of the slot is a piece of it)
     if (s.h_meta) (void)hipHostFree(s.h_meta);
+    if (s.h_routes) (void)hipHostFree(s.h_routes);
     for (hipEvent_t ev : {s.uploaded, s.formatted, s.fetched})
       if (ev) (void)hipEventDestroy(ev);
   }
@@ -1194,7 +1208,16 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
   // a second capture exists only in single-end chains (cs_cap2)
   t->needs_cap2 = !eng->paired && params->has_umi;
   t->compress = params->compress != 0;
-  t->max_chunks = (uint32_t)((out_cap + csdefl::kChunk - 1) / csdefl::kChunk) + 3u;
+  if (params->n_bins) {
+    if (params->n_bins > 255u || eng->demux_mate < 0) {
+      delete t;
+      return fail(CS_ERR_ARG, "n_bins = %u needs a plan with a demultiplexing op (and at most 255 barcodes)", params->n_bins);
+    }
+    t->tp.n_bins = (uint16_t)params->n_bins;
+    t->tp.demux_mate = (uint8_t)eng->demux_mate;
+    t->n_routes = 3u + params->n_bins;
+  }
+  t->max_chunks = (uint32_t)((out_cap + csdefl::kChunk - 1) / csdefl::kChunk) + t->n_routes;
   t->seg_blocks = (uint32_t)((max_text_bytes + cstext::kSeg - 1) / cstext::kSeg);
   t->fmt_blocks = (max_records + 255u) / 256u;
 #define TXT_TRY(expr)                                                                       \
@@ -1274,9 +1297,11 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
       }
     }
     const size_t o_cap2 = t->needs_cap2 ? reserve((size_t)max_records * sizeof(cs_cap2)) : 0;
-    const size_t o_blk = reserve(((size_t)2 * (t->seg_blocks + 1) + (size_t)6 * (t->fmt_blocks + 1)) * sizeof(uint32_t));
-    const size_t o_totals = reserve(8 * sizeof(unsigned long long));
+    const size_t o_blk = reserve(((size_t)2 * (t->seg_blocks + 1) + (size_t)2 * t->n_routes * (t->fmt_blocks + 1)) * sizeof(uint32_t));
+    const size_t o_totals = reserve((2 + 2 * (size_t)t->n_routes) * sizeof(unsigned long long));
     const size_t o_meta = reserve(sizeof(cstext::TextMeta));
+    const size_t o_bc = t->tp.n_bins ? reserve(max_records) : 0;
+    const size_t o_routes = t->tp.n_bins ? reserve(sizeof(RouteBlock)) : 0;
     TXT_TRY(hipMalloc(&s.d_arena, need));
     uint8_t *base = s.d_arena;
     TXT_TRY(hipMemsetAsync(base, 0, zero_bytes, t->h2d));
@@ -1306,6 +1331,11 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
     s.d_blk = reinterpret_cast<uint32_t *>(base + o_blk);
     s.d_totals = reinterpret_cast<unsigned long long *>(base + o_totals);
     s.d_meta = reinterpret_cast<cstext::TextMeta *>(base + o_meta);
+    if (t->tp.n_bins) {
+      s.d_bc = base + o_bc;
+      s.d_routes = reinterpret_cast<RouteBlock *>(base + o_routes);
+      TXT_TRY(hipHostMalloc(&s.h_routes, sizeof(RouteBlock), hipHostMallocPortable));
+    }
     TXT_TRY(hipHostMalloc(&s.h_meta, sizeof(cstext::TextMeta), hipHostMallocPortable));
     TXT_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
     TXT_TRY(hipEventCreateWithFlags(&s.formatted, hipEventDisableTiming));
@@ -1391,7 +1421,7 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
       rd[m].len = s.d_len[m];
       rd[m].out = s.d_res[m];
       rd[m].cap2 = (m == 0) ? s.d_cap2 : nullptr;
-      rd[m].bc = nullptr;
+      rd[m].bc = (t->tp.n_bins && m == eng->demux_mate) ? s.d_bc : nullptr;
     }
     int rc = launch(eng, st, rs, &rd[0], mates == 2 ? &rd[1] : nullptr, n_records, t->stride, false, &s.d_meta->err);
     if (rc) return rc;
@@ -1417,9 +1447,20 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
     fa.totals = s.d_totals + 2;
     fa.meta = s.d_meta;
     const uint32_t fb = (n_records + 255u) / 256u;
-    hipLaunchKernelGGL(cstext::format_sizes, dim3(fb), dim3(256), 0, rs, fa, t->tp);
-    hipLaunchKernelGGL(cstext::text_scan_blocks, dim3(1), dim3(1024), 0, rs, blk_fmt, fb, 6u, fa.totals);
-    hipLaunchKernelGGL(cstext::format_offsets, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+    if (t->tp.n_bins) {  // one route per barcode: LDS sums per route instead of a block scan per route
+      fa.bc = s.d_bc;
+      fa.route_bytes = &s.d_routes->bytes[0][0];
+      fa.route_count = s.d_routes->count;
+      const uint32_t cols = 2u * t->n_routes;
+      HIP_TRY(hipMemsetAsync(s.d_routes, 0, sizeof(RouteBlock), rs));
+      hipLaunchKernelGGL(cstext::format_sizes_bins, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+      hipLaunchKernelGGL(cstext::text_scan_blocks, dim3(cols < 64u ? cols : 64u), dim3(1024), 0, rs, blk_fmt, fb, cols, fa.totals);
+      hipLaunchKernelGGL(cstext::format_offsets_bins, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+    } else {
+      hipLaunchKernelGGL(cstext::format_sizes, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+      hipLaunchKernelGGL(cstext::text_scan_blocks, dim3(1), dim3(1024), 0, rs, blk_fmt, fb, 6u, fa.totals);
+      hipLaunchKernelGGL(cstext::format_offsets, dim3(fb), dim3(256), 0, rs, fa, t->tp);
+    }
     const unsigned long long items = (unsigned long long)n_records * mates;
     const unsigned long long want = (items * 32ull + 255ull) / 256ull;
     hipLaunchKernelGGL(cstext::format_copy, dim3((uint32_t)(want > 32768ull ? 32768ull : want)), dim3(256), 0, rs, fa, t->tp);
@@ -1428,7 +1469,8 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
       for (int m = 0; m < mates; ++m) {
         csdefl::DeflateArgs da;
         da.text = s.d_out[m];
-        da.route_bytes = &s.d_meta->route_bytes[0][m];
+        da.route_bytes = t->tp.n_bins ? &s.d_routes->bytes[0][m] : &s.d_meta->route_bytes[0][m];
+        da.n_routes = t->n_routes;
         da.stage = s.d_gzstage[m];
         da.info = s.d_chunk[m];
         da.max_chunks = t->max_chunks;
@@ -1437,9 +1479,10 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
         csdefl::LayoutArgs la;
         la.info = s.d_chunk[m];
         la.route_bytes = da.route_bytes;
+        la.n_routes = t->n_routes;
         la.chunk_dst = s.d_chunk_dst[m];
         la.gz = s.d_gz[m];
-        la.gz_route_bytes = &s.d_meta->gz_route_bytes[0][m];
+        la.gz_route_bytes = t->tp.n_bins ? &s.d_routes->gz_bytes[0][m] : &s.d_meta->gz_route_bytes[0][m];
         la.gz_total = &s.d_meta->gz_bytes[m];
         la.gate = da.gate;
         hipLaunchKernelGGL(csdefl::deflate_layout, dim3(1), dim3(256), 0, rs, la);
@@ -1449,6 +1492,7 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
         ca.stage = s.d_gzstage[m];
         ca.gz = s.d_gz[m];
         ca.route_bytes = da.route_bytes;
+        ca.n_routes = t->n_routes;
         ca.gate = da.gate;
         hipLaunchKernelGGL(csdefl::deflate_compact, dim3(t->max_chunks), dim3(256), 0, rs, ca);
       }
@@ -1459,6 +1503,10 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
     HIP_TRY(hipStreamWaitEvent(rs, s.fetched, 0));
   }
   HIP_TRY(hipMemcpyAsync(s.h_meta, s.d_meta, sizeof(cstext::TextMeta), hipMemcpyDeviceToHost, rs));
+  if (t->tp.n_bins) {
+    if (!n_records) HIP_TRY(hipMemsetAsync(s.d_routes, 0, sizeof(RouteBlock), rs));
+    HIP_TRY(hipMemcpyAsync(s.h_routes, s.d_routes, sizeof(RouteBlock), hipMemcpyDeviceToHost, rs));
+  }
   HIP_TRY(hipEventRecord(s.formatted, rs));
   s.busy = true;
   return CS_OK;
@@ -1493,6 +1541,14 @@ int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
       }
     res->out_bytes[0] = m.gz_bytes[0];
     res->out_bytes[1] = m.gz_bytes[1];
+    if (t->tp.n_bins)  // (the gzip sizes of a demultiplexing plan live in the route block: [0] = every barcode together)
+      for (int k = 0; k < 2; ++k) {
+        const RouteBlock &rb = *s.h_routes;
+        res->route_bytes[1][k] = rb.gz_bytes[1][k];
+        res->route_bytes[2][k] = rb.gz_bytes[2][k];
+        res->route_bytes[0][k] = rb.gz_bytes[0][k];
+        for (uint32_t q = 3; q < t->n_routes; ++q) res->route_bytes[0][k] += rb.gz_bytes[q][k];
+      }
   }
   res->written_bp[0] = m.written_bp[0];
   res->written_bp[1] = m.written_bp[1];
@@ -1505,6 +1561,24 @@ int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res) {
     s.busy = false;
   }
   s.waited = true;
+  return CS_OK;
+}
+
+int cs_text_routes(cs_text *t, uint32_t slot, uint64_t *bytes, uint64_t *text_bytes, uint32_t *count) {
+  if (!t) return fail(CS_ERR_ARG, "null text engine");
+  if (slot >= t->slots.size()) return fail(CS_ERR_ARG, "slot %u out of range", slot);
+  TextSlot &s = t->slots[slot];
+  if (!s.waited) return fail(CS_ERR_STATE, "slot %u: cs_text_wait first", slot);
+  const cstext::TextMeta &m = *s.h_meta;
+  for (uint32_t q = 0; q < t->n_routes; ++q)
+    for (int k = 0; k < 2; ++k) {
+      const unsigned long long raw = t->tp.n_bins ? s.h_routes->bytes[q][k] : m.route_bytes[q][k];
+      const unsigned long long gz = t->tp.n_bins ? s.h_routes->gz_bytes[q][k] : m.gz_route_bytes[q][k];
+      if (text_bytes) text_bytes[q * 2 + k] = raw;
+      if (bytes) bytes[q * 2 + k] = t->compress ? gz : raw;
+    }
+  if (count)
+    for (uint32_t q = 0; q < t->n_routes; ++q) count[q] = t->tp.n_bins ? s.h_routes->count[q] : m.route_count[q];
   return CS_OK;
 }
 

@@ -322,7 +322,9 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
     devices = [int(x) for x in want.split(",")] if want else list(range(n_dev))
     # Text path (default): the device parses the records and formats the output (textio.py / cs_text_*); the host
     # path below (native parser / formatter in a thread pool) stays for demultiplexing runs and as CUTSEQ_TEXT_PATH=0.
-    if tp.demux is None and os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
+    # (demultiplexing on long barcodes -- the op's "own ops" form -- stays on the round-2 host path: the text engine
+    # knows the table form only)
+    if (tp.demux is None or tp.demux.tabulated) and os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
         from . import textio
         return textio.run_text_pipeline(args, tp, devices, _block_records(args, len(devices)),
                                         shares=shares)
@@ -483,7 +485,7 @@ def run_cutseq(args, argv=None):
         return totals
     if getattr(args, "ranks", 1) > 1:
         if tp.demux is not None or os.environ.get("CUTSEQ_TEXT_PATH", "1") == "0":
-            logging.warning("--ranks ignored: it needs the text path (no demultiplexing).")
+            logging.warning("--ranks ignored: it needs the text path without demultiplexing.")
         else:
             from . import ranks
             totals = ranks.run_parent(list(sys.argv[1:] if argv is None else argv), args, tp)

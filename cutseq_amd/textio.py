@@ -465,10 +465,10 @@ class StreamWriter:
 
 
 class _Done:
-    __slots__ = ("k", "n", "res", "out")
+    __slots__ = ("k", "n", "res", "out", "sizes", "counts")
 
-    def __init__(self, k, n, res, out):
-        self.k, self.n, self.res, self.out = k, n, res, out
+    def __init__(self, k, n, res, out, sizes=None, counts=None):
+        self.k, self.n, self.res, self.out, self.sizes, self.counts = k, n, res, out, sizes, counts
 
 
 class TextWorker(threading.Thread):
@@ -476,9 +476,10 @@ class TextWorker(threading.Thread):
 
     SLOTS = 3
 
-    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int, compress: bool = False):
+    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int, compress: bool = False, bins: int = 0):
         super().__init__(daemon=True, name=f"cutseq-gpu{device}")
         self.tp, self.device, self.done, self.chunk_reads, self.compress = tp, device, done, chunk_reads, compress
+        self.bins = bins  # demultiplexing: one route per barcode behind the three ordinary ones
         self.inbox: "queue.Queue" = queue.Queue(maxsize=self.SLOTS)
         self.engine = self.text = None
         self.stride, self.capacity, self.want_stride = 152, 0, 152
@@ -505,7 +506,8 @@ class TextWorker(threading.Thread):
         self.stride = max(self.stride, stride)
         self.capacity = max(self.capacity, int(text_bytes * 1.25) + (1 << 20))
         self.text = textpath.TextEngine(self.engine, slots=self.SLOTS, max_text_bytes=self.capacity,
-                                        max_records=self.chunk_reads, stride=self.stride, compress=self.compress)
+                                        max_records=self.chunk_reads, stride=self.stride, compress=self.compress,
+                                        bins=self.bins)
         self.submitted = 0
 
     def _submit(self, inflight: deque, k: int, b1: TextBlock, b2: Optional[TextBlock]):
@@ -538,6 +540,9 @@ class TextWorker(threading.Thread):
         # than the rows so far (2 x 250, 2 x 300) should not stay there: longer rows from the next batch on.
         if max(res.n_long) * 64 > b1.n and self.stride < abi.CS_MAX_STRIDE:
             self.want_stride = max(self.want_stride, min(abi.CS_MAX_STRIDE, (int(res.max_len) + 3) // 4 * 4))
+        sizes = counts = None
+        if self.bins:
+            sizes, _, counts = self.text.routes(slot)
         out = [fastq.PINNED.take(max(int(res.out_bytes[m]), 1)) for m in range(2 if b2 is not None else 1)]
         t0 = _tick("take", t0)
         self.text.fetch(slot, out[0], out[1] if b2 is not None else None)
@@ -545,7 +550,7 @@ class TextWorker(threading.Thread):
         b1.release()
         if b2 is not None:
             b2.release()
-        self.done.put(_Done(k, b1.n, res, out))
+        self.done.put(_Done(k, b1.n, res, out, sizes, counts))
 
     def run(self):
         inflight: deque = deque()
@@ -595,7 +600,11 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
 
         # every output a ".gz" file: the device compresses (deflate_kernels.hip.inc) and the writers pass the members
         # through; otherwise text comes back and ".gz" outputs are deflated in the host pool (CUTSEQ_GPU_DEFLATE=0 too)
-        names_all = [n for group in (args.output_file, args.short_file, args.untrimmed_file) for n in group if n]
+        # demultiplexing (table form): the trimmed pairs of barcode b are route 3 + b, one pair of files each
+        n_bins = len(tp.demux.barcodes) if tp.demux is not None else 0
+        bin_files = list(getattr(args, "demux_files", None) or []) if n_bins else []
+        names_all = [n for group in [args.output_file if not n_bins else [], args.short_file, args.untrimmed_file] + bin_files
+                     for n in group if n]
         compress = bool(names_all) and all(n.endswith(".gz") for n in names_all) and os.environ.get("CUTSEQ_GPU_DEFLATE", "1") != "0"
 
         def mk(names):
@@ -606,10 +615,13 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
                     opened.append(group[-1])
             return group
 
-        trimmed = mk(args.output_file)
+        trimmed = mk(args.output_file) if not n_bins else [None] * len(args.output_file)
         if paired and tp.swap_outputs:
             trimmed = trimmed[::-1]
         outs = [trimmed, mk(args.short_file), mk(args.untrimmed_file)]
+        for names in bin_files:
+            files = mk(names)
+            outs.append(files[::-1] if paired and tp.swap_outputs else files)
     except BaseException:
         r1.close()
         if r2 is not None:
@@ -626,22 +638,29 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         from .run import _phase
         _phase("readers and writers open")
     done: "queue.Queue" = queue.Queue()
-    workers = [TextWorker(tp, dev, done, chunk_reads, compress) for dev in devices]
+    workers = [TextWorker(tp, dev, done, chunk_reads, compress, n_bins) for dev in devices]
+    if n_bins:
+        totals["routes"] += [0] * n_bins
     budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk
     failure: List[BaseException] = []
 
     def emit(item: _Done):
         res = item.res
         totals["in_pairs"] += item.n
-        for q in range(3):
-            totals["routes"][q] += int(res.route_count[q])
+        if item.counts is not None:  # (demultiplexing: [0] stays 0, the barcodes' pairs are routes 3 ..)
+            for q in range(len(item.counts)):
+                totals["routes"][q] += int(item.counts[q])
+        else:
+            for q in range(3):
+                totals["routes"][q] += int(res.route_count[q])
         for m in range(2 if paired else 1):
             totals["written_bp"][m] += int(res.written_bp[m])
+        sizes = item.sizes if item.sizes is not None else res.route_bytes
         jobs = []
         for m in range(2 if paired else 1):
             at = 0
-            for route in range(3):
-                nbytes = int(res.route_bytes[route][m])
+            for route in range(len(outs)):
+                nbytes = int(sizes[route][m])
                 fh = (outs[route] + [None])[m]
                 if nbytes and fh is not None:
                     jobs.append((fh, memoryview(item.out[m])[at:at + nbytes]))
@@ -746,7 +765,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         totals["in_bp"][m] = sum(int(pair[m]["in_bp"]) for pair in stats)
         totals["out_bp"][m] = sum(int(pair[m]["out_bp"]) for pair in stats)
     totals["seconds"] = time.perf_counter() - t_start
-    totals["bin_names"] = None
+    totals["bin_names"] = list(args.demux[0]) if n_bins else None
     totals["stats"] = stats
     totals["devices"] = devices
     totals["path"] = "text"

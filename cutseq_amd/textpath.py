@@ -65,9 +65,10 @@ class TextEngine:
     """``slots`` batches in flight on one :class:`TrimEngine` (its plan, streams and statistics block)."""
 
     def __init__(self, engine: TrimEngine, slots: int = 3, max_text_bytes: int = 64 << 20, max_records: int = 1 << 18,
-                 stride: int = 152, compress: bool = False):
+                 stride: int = 152, compress: bool = False, bins: int = 0):
         """``compress``: every route's output leaves the device as one gzip member (``res.route_bytes`` then counts
-        compressed bytes): what ``.gz`` output files take as they are."""
+        compressed bytes): what ``.gz`` output files take as they are.  ``bins``: the plan demultiplexes (table form)
+        into that many barcodes; the trimmed records of barcode b are route 3 + b (:meth:`routes`)."""
         self.L = capi.load()
         self.engine = engine
         plan = engine.plan
@@ -78,6 +79,8 @@ class TextEngine:
         p.reverse_complement = 1 if plan.reverse_complement else 0
         p.compress = 1 if compress else 0
         self.compress = bool(compress)
+        p.n_bins = int(bins)
+        self.n_routes = 3 + int(bins)
         p.max_tag = max_tag(plan)
         self._keep = []  # the literals must outlive the call
         for field, chain in (("suffix1", plan.r1), ("suffix2", plan.r2)):
@@ -126,6 +129,14 @@ class TextEngine:
                                   f"{res.n_lines[0]} / {res.n_lines[1]} line ends)")
         return res
 
+    def routes(self, slot: int):
+        """Behind :meth:`wait`: (bytes[route, mate] as fetched, text_bytes[route, mate], count[route]) of every route."""
+        got = np.zeros((self.n_routes, 2), dtype=np.uint64)
+        raw = np.zeros((self.n_routes, 2), dtype=np.uint64)
+        count = np.zeros(self.n_routes, dtype=np.uint32)
+        capi.check(self.L.cs_text_routes(self._h, slot, got.ctypes.data, raw.ctypes.data, count.ctypes.data))
+        return got, raw, count
+
     def fetch(self, slot: int, dst1, dst2=None) -> None:
         """Output text of the batch into the caller's buffers (``res.out_bytes[m]`` bytes each); frees the slot."""
         capi.check(self.L.cs_text_fetch(self._h, slot, _address(dst1) or None, _address(dst2) or None))
@@ -134,18 +145,23 @@ class TextEngine:
         """Synchronous convenience wrapper (tests): -> (streams[route][mate] bytes, counts[route])."""
         self.submit(slot, text1, len(text1), text2, len(text2) if text2 is not None else 0, n_records)
         res = self.wait(slot)
+        got, _, count = self.routes(slot)
         out = [np.empty(max(int(res.out_bytes[m]), 1), dtype=np.uint8) for m in range(2)]
         self.fetch(slot, out[0], out[1] if text2 is not None else None)
+        if self.n_routes > 3:
+            return split_routes(got, out, text2 is not None), [int(c) for c in count]
         return split_routes(res, out, text2 is not None), [int(c) for c in res.route_count]
 
 
-def split_routes(res: abi.cs_text_result, out, paired: bool):
-    """-> streams[route][mate] (bytes) from the per-mate buffers :meth:`TextEngine.fetch` filled."""
-    streams = [[b"", b""] for _ in range(3)]
+def split_routes(res, out, paired: bool):
+    """-> streams[route][mate] (bytes) from the per-mate buffers :meth:`TextEngine.fetch` filled.  ``res``: the
+    ``cs_text_result`` of the batch, or the bytes[route, mate] array of :meth:`TextEngine.routes`."""
+    sizes = res.route_bytes if isinstance(res, abi.cs_text_result) else res
+    streams = [[b"", b""] for _ in range(len(sizes))]
     for m in range(2 if paired else 1):
         at = 0
-        for route in range(3):
-            n = int(res.route_bytes[route][m])
+        for route in range(len(sizes)):
+            n = int(sizes[route][m])
             streams[route][m] = out[m][at:at + n].tobytes()
             at += n
     return streams

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 4
+#define CS_ABI_VERSION 5
 #define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
 #define CS_MAX_OPS 24      /* longest per-mate op chain                           */
 #define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
@@ -297,6 +297,10 @@ typedef struct cs_text_params {
   uint32_t max_tag;           /* most bytes a record name can gain: 1 + the plan's capture lengths (0 = no UMI) */
   const char *suffix1[2];     /* SuffixRemover literals of mate 1, applied in order (NULL = none)               */
   const char *suffix2[2];
+  uint32_t n_bins;            /* plans with a CS_OP_DEMUX op (table form): the number of barcodes.  The trimmed
+                                 records of barcode b then form route 3 + b (route 0 stays empty): 3 + n_bins streams
+                                 per mate, back to back in route order; sizes through cs_text_routes.  0: no bins */
+  uint32_t _reserved;
 } cs_text_params;
 
 typedef struct cs_text_result {
@@ -304,7 +308,7 @@ typedef struct cs_text_result {
   uint32_t error_record;      /* first offending record of the batch                                            */
   uint32_t max_len;           /* longest read of the batch                                                      */
   uint32_t n_records;
-  uint32_t route_count[3];    /* records (pairs) per route                                                      */
+  uint32_t route_count[3];    /* records (pairs) per route (n_bins > 0: [0] = all barcodes together; likewise below) */
   uint32_t _pad;
   uint64_t route_bytes[3][2]; /* [route][mate]                                                                  */
   uint64_t out_bytes[2];      /* per mate: sum over the routes = what cs_text_fetch copies                      */
@@ -327,6 +331,10 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
                    uint32_t n_records);
 /* Blocks until the slot's batch is formatted on the device; sizes and errors in *res. */
 int cs_text_wait(cs_text *t, uint32_t slot, cs_text_result *res);
+/* Behind cs_text_wait: the sizes of every route stream, 3 + n_bins of them: bytes[route][mate] as cs_text_fetch
+ * delivers them (gzip members if compress), text_bytes[route][mate] uncompressed, count[route] records.  The streams of
+ * a mate lie in route order in the fetched buffer.  Any of the three pointers may be NULL. */
+int cs_text_routes(cs_text *t, uint32_t slot, uint64_t *bytes, uint64_t *text_bytes, uint32_t *count);
 /* Copies the output text (res->out_bytes[m] bytes per mate) into the caller's buffers and blocks until it is
  * there; the slot is free for the next cs_text_submit afterwards.  dst2 == NULL for single-end. */
 int cs_text_fetch(cs_text *t, uint32_t slot, void *dst1, void *dst2);

@@ -208,3 +208,64 @@ def test_device_compressed_output_is_gzip_of_the_same_text(n):
     if n >= 3000:
         ratio = sum(len(x) for row in plain for x in row) / sum(len(x) for row in packed for x in row)
         assert ratio > 2.5, ratio  # Huffman-only: ~2 bits per base / quality value, headers a little over 4
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_text_path_demultiplexes_into_one_route_per_barcode(compress):
+    """cs_text_params.n_bins: the trimmed records of barcode b leave the device as route 3 + b (plain text or one gzip
+    member per route), in input order; short and untrimmed pairs keep routes 1 and 2.  Expected: the array API's
+    results and barcode indices for the same reads (held to the oracle by tests/test_gpu_demux.py), formatted by the
+    record logic."""
+    import gzip
+    import random
+    from cutseq_amd import hostfmt
+    from test_gpu_demux import barcode_set, plant_barcodes, scheme_with
+    rng = random.Random(77)
+    codes = barcode_set(rng, 24, 8, 4)
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    st.min_length = 40
+    st.demux_barcodes = codes
+    n = 20_000
+    batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=8, adapter_fraction=0.5)
+    plant_barcodes(rng, batch, codes, 8)
+    tp = planmod.compile_paired(BarcodeConfig(scheme_with(codes[0])), st)
+    names1 = [s.encode() for s in synth.headers(n, 1)]
+    names2 = [s.encode() for s in synth.headers(n, 2)]
+    text1 = fastq_text(names1, batch.seq1, batch.qual1, batch.len1)
+    text2 = fastq_text(names2, batch.seq2, batch.qual2, batch.len2)
+    bc = np.empty(n, dtype=np.uint8)
+    with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
+        r1, _, r2 = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
+        eng.wait(0)
+    want = [[b"", b""] for _ in range(3 + len(codes))]
+    want_counts = [0] * (3 + len(codes))
+    for i in range(n):
+        n1, n2 = int(batch.len1[i]), int(batch.len2[i])
+        route, rec1, rec2 = hostfmt.format_pair(names1[i], batch.seq1[i, :n1].tobytes(), batch.qual1[i, :n1].tobytes(), r1[i],
+                                                names2[i], batch.seq2[i, :n2].tobytes(), batch.qual2[i, :n2].tobytes(), r2[i], tp)
+        if route == 0:
+            assert bc[i] != abi.CS_DEMUX_NONE
+            route = 3 + int(bc[i])
+        want[route][0] += rec1
+        want[route][1] += rec2
+        want_counts[route] += 1
+    assert sum(1 for c in want_counts[3:] if c) == len(codes) and want_counts[1] > 100 and want_counts[2] > 100
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=2, max_text_bytes=len(text1) + 1024, max_records=n, stride=batch.stride,
+                                 compress=compress, bins=len(codes)) as te:
+            for _ in range(2):  # (a slot's second batch: the route block is reset)
+                got, counts = te.run(text1, n, text2)
+                assert counts == want_counts
+                for route in range(3 + len(codes)):
+                    for m in range(2):
+                        data = got[route][m]
+                        if compress and data:
+                            data = gzip.decompress(data)
+                        assert data == want[route][m], (route, m)
+            res = None
+            te.submit(1, text1, len(text1), text2, len(text2), n)
+            res = te.wait(1)
+            assert int(res.route_count[0]) == sum(want_counts[3:]) and int(res.route_count[1]) == want_counts[1]
+            out = [np.empty(max(int(res.out_bytes[m]), 1), dtype=np.uint8) for m in range(2)]
+            te.fetch(1, out[0], out[1])
