@@ -597,6 +597,47 @@ def test_one_huge_gzip_member_decodes_in_parallel(tmp_path, monkeypatch):
         live.clear()  # (what an aborted read still holds goes with the garbage collector)
 
 
+def test_damaged_huge_member_never_passes_silently(tmp_path, monkeypatch):
+    """Random damage to a single-member file (bit flips, truncation, overwritten and deleted stretches) through the
+    parallel decoder: every case ends in OSError (or, for damage the format cannot see, in the right bytes) -- never in
+    wrong text, never in a hang."""
+    import os
+    import random
+    from cutseq_amd import codec
+    rng = random.Random(11)
+    body = "".join(f"@SIM:{i} 1:N:0:X\n{''.join(rng.choice('ACGT') for _ in range(100))}\n+\n"
+                   f"{''.join(rng.choice('FFFFFF:,#') for _ in range(100))}\n" for i in range(30_000)).encode()
+    good = gzip.compress(body, 1)
+    monkeypatch.setattr(codec, "_MEMBER_CAP", 1 << 20)
+    path = tmp_path / "damaged.fq.gz"
+    errors = 0
+    for it in range(60):
+        blob = bytearray(good)
+        kind = it % 4
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                blob[rng.randrange(len(blob))] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            blob = blob[:rng.randrange(20, len(blob))]
+        elif kind == 2:
+            a = rng.randrange(len(blob))
+            b = min(len(blob), a + rng.randrange(1, 5000))
+            blob[a:b] = os.urandom(b - a)
+        else:
+            a = rng.randrange(len(blob))
+            del blob[a:a + rng.randrange(1, 2000)]
+        path.write_bytes(bytes(blob))
+        src = codec.GzipSource(str(path), fastq._pool())
+        try:
+            got = b"".join(bytes(memoryview(a)[:n]) for a, n in src.blocks())
+            assert got == body, f"damage of kind {kind} (iteration {it}) went through with different text"
+        except OSError:
+            errors += 1
+        finally:
+            src.close()
+    assert errors >= 55
+
+
 def test_barcode_names_must_be_usable_in_file_names(tmp_path):
     from cutseq_amd import demux
     good = tmp_path / "ok.tsv"
