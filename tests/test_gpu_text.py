@@ -210,8 +210,8 @@ def test_device_compressed_output_is_gzip_of_the_same_text(n):
         assert ratio > 2.5, ratio  # Huffman-only: ~2 bits per base / quality value, headers a little over 4
 
 
-@pytest.mark.parametrize("compress", [False, True])
-def test_text_path_demultiplexes_into_one_route_per_barcode(compress):
+@pytest.mark.parametrize("compress,paired", [(False, True), (True, True), (False, False)])
+def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired):
     """cs_text_params.n_bins: the trimmed records of barcode b leave the device as route 3 + b (plain text or one gzip
     member per route), in input order; short and untrimmed pairs keep routes 1 and 2.  Expected: the array API's
     results and barcode indices for the same reads (held to the oracle by tests/test_gpu_demux.py), formatted by the
@@ -227,23 +227,29 @@ def test_text_path_demultiplexes_into_one_route_per_barcode(compress):
     st.min_length = 40
     st.demux_barcodes = codes
     n = 20_000
-    batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=8, adapter_fraction=0.5)
+    batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=8, adapter_fraction=0.5, single_end=not paired)
     plant_barcodes(rng, batch, codes, 8)
-    tp = planmod.compile_paired(BarcodeConfig(scheme_with(codes[0])), st)
+    tp = (planmod.compile_paired if paired else planmod.compile_single)(BarcodeConfig(scheme_with(codes[0])), st)
     names1 = [s.encode() for s in synth.headers(n, 1)]
     names2 = [s.encode() for s in synth.headers(n, 2)]
     text1 = fastq_text(names1, batch.seq1, batch.qual1, batch.len1)
-    text2 = fastq_text(names2, batch.seq2, batch.qual2, batch.len2)
+    text2 = fastq_text(names2, batch.seq2, batch.qual2, batch.len2) if paired else None
     bc = np.empty(n, dtype=np.uint8)
     with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
-        r1, _, r2 = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
+        r1, cap2, r2 = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
         eng.wait(0)
     want = [[b"", b""] for _ in range(3 + len(codes))]
     want_counts = [0] * (3 + len(codes))
     for i in range(n):
-        n1, n2 = int(batch.len1[i]), int(batch.len2[i])
-        route, rec1, rec2 = hostfmt.format_pair(names1[i], batch.seq1[i, :n1].tobytes(), batch.qual1[i, :n1].tobytes(), r1[i],
-                                                names2[i], batch.seq2[i, :n2].tobytes(), batch.qual2[i, :n2].tobytes(), r2[i], tp)
+        n1 = int(batch.len1[i])
+        if paired:
+            n2 = int(batch.len2[i])
+            route, rec1, rec2 = hostfmt.format_pair(names1[i], batch.seq1[i, :n1].tobytes(), batch.qual1[i, :n1].tobytes(), r1[i],
+                                                    names2[i], batch.seq2[i, :n2].tobytes(), batch.qual2[i, :n2].tobytes(), r2[i], tp)
+        else:
+            route, rec1 = hostfmt.format_single(names1[i], batch.seq1[i, :n1].tobytes(), batch.qual1[i, :n1].tobytes(), r1[i],
+                                                cap2[i] if cap2 is not None else None, tp)
+            rec2 = b""
         if route == 0:
             assert bc[i] != abi.CS_DEMUX_NONE
             route = 3 + int(bc[i])
@@ -264,8 +270,8 @@ def test_text_path_demultiplexes_into_one_route_per_barcode(compress):
                             data = gzip.decompress(data)
                         assert data == want[route][m], (route, m)
             res = None
-            te.submit(1, text1, len(text1), text2, len(text2), n)
+            te.submit(1, text1, len(text1), text2, len(text2) if paired else 0, n)
             res = te.wait(1)
             assert int(res.route_count[0]) == sum(want_counts[3:]) and int(res.route_count[1]) == want_counts[1]
             out = [np.empty(max(int(res.out_bytes[m]), 1), dtype=np.uint8) for m in range(2)]
-            te.fetch(1, out[0], out[1])
+            te.fetch(1, out[0], out[1] if paired else None)
