@@ -320,6 +320,9 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
             logging.warning("-t/--threads ignored: the host thread pool of this process is already running.")
     want = os.environ.get("CUTSEQ_DEVICES")  # e.g. "0,1,2,3"; a device may be listed twice (two engines on it)
     devices = [int(x) for x in want.split(",")] if want else list(range(n_dev))
+    if any(d < 0 or d >= n_dev for d in devices):
+        _fail(f"GPU {max(devices)} does not exist: this process sees {n_dev} (--ranks N puts rank r on GPU r; "
+              "CUTSEQ_DEVICES=0,0,... lists the GPUs to use, one entry per rank or worker, repeats allowed).")
     # Text path (default): the device parses the records and formats the output (textio.py / cs_text_*); the host
     # path below (native parser / formatter in a thread pool) stays for demultiplexing runs and as CUTSEQ_TEXT_PATH=0.
     # (demultiplexing on long barcodes -- the op's "own ops" form -- stays on the round-2 host path: the text engine
