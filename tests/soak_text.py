@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Text-path soak on a GPU box (not collected by pytest): the chain presets through cs_text_* on fresh synthetic reads with
+seeds nobody looked at -- ragged lengths, odd batch sizes, plain and device-compressed output, names with and without
+mate suffixes -- against the oracle's results formatted by the record logic, byte for byte, until the time budget is spent.
+
+    python tests/soak_text.py [seconds] [first_seed]
+"""
+import gzip
+import random
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+import numpy as np  # noqa: E402
+
+import test_gpu_text as tt  # noqa: E402
+import util  # noqa: E402
+from cutseq_amd import plan as planmod, synth, textpath  # noqa: E402
+from cutseq_amd.common import BUILDIN_ADAPTERS  # noqa: E402
+from cutseq_amd.engine import TrimEngine  # noqa: E402
+from test_oracle import CHAIN_CASES  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
+    cases = [c for c in CHAIN_CASES if "shortcut" not in c[1]]
+    t0 = time.time()
+    done = 0
+    while time.time() - t0 < budget:
+        rng = random.Random(seed)
+        name, flags, paired = cases[rng.randrange(len(cases))]
+        scheme = BUILDIN_ADAPTERS.get(name, name)
+        st = planmod.CutadaptConfig()
+        for k, v in flags.items():
+            setattr(st, k, v)
+        st.min_length = rng.choice([0, 20, 60])
+        read_len = rng.choice([36, 75, 100, 150, 151, 250])
+        n = rng.choice([1, 63, 64, 65, 257, 3000, 20_000])
+        batch = synth.generate_pairs(n, read_len, scheme, seed=seed, single_end=not paired,
+                                     poly_fraction=rng.choice([0.02, 0.2]), art5_fraction=rng.choice([0.001, 0.05]),
+                                     adapter_fraction=rng.choice([0.2, 0.6]))
+        nrng = np.random.default_rng(seed)
+        cut = nrng.random(n) < 0.15
+        batch.len1[cut] = nrng.integers(0, read_len, size=int(cut.sum())).astype(np.uint16)
+        if paired:
+            batch.len2[cut] = nrng.integers(0, read_len, size=int(cut.sum())).astype(np.uint16)
+        tp = util.compile_plan(scheme, st, paired, untrimmed_requested="INLINE" in name)
+        style = rng.randrange(3)
+        names1 = [(f"S{seed}:{i}/1" if style == 0 else f"S{seed}:{i} 1:N:0:X" if style == 1 else f"S{seed}.{i}.1").encode() for i in range(n)]
+        names2 = [(f"S{seed}:{i}/2" if style == 0 else f"S{seed}:{i} 2:N:0:X" if style == 1 else f"S{seed}.{i}.2").encode() for i in range(n)] if paired else None
+        want, want_counts = tt.expected_streams(tp, batch, names1, names2)
+        eol = rng.choice([b"\n", b"\r\n"])
+        text1 = tt.fastq_text(names1, batch.seq1, batch.qual1, batch.len1, eol, rng.random() < 0.5)
+        text2 = tt.fastq_text(names2, batch.seq2, batch.qual2, batch.len2, eol, True) if paired else None
+        compress = rng.random() < 0.4
+        with TrimEngine(tp, device=0, slots=0) as eng:
+            with textpath.TextEngine(eng, slots=2, max_text_bytes=max(len(text1), len(text2 or b""), 1) + 1024, max_records=max(n, 1),
+                                     stride=rng.choice([batch.stride, batch.stride + 8, 64 if read_len > 64 else batch.stride]),
+                                     compress=compress) as te:
+                got, counts = te.run(text1, n, text2, slot=rng.randrange(2))
+        assert counts == want_counts, (seed, name, counts, want_counts)
+        for route in range(3):
+            for m in range(2 if paired else 1):
+                data = got[route][m]
+                if compress and data:
+                    data = gzip.decompress(data)
+                assert data == want[route][m], (seed, name, route, m)
+        done += 1
+        seed += 1
+        if done % 50 == 0:
+            print(f"{time.time() - t0:6.0f} s  seed {seed}  batches {done}", flush=True)
+    print(f"text soak ok: {done} batches, seeds up to {seed}, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
