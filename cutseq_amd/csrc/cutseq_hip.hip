@@ -1170,8 +1170,6 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
   if (!out) return fail(CS_ERR_ARG, "out is null");
   *out = nullptr;
   if (!eng || !params) return fail(CS_ERR_ARG, "null engine or params");
-  if (eng->long_demux)  // (the kernel for reads longer than the rows knows the table form of CS_OP_DEMUX only)
-    return fail(CS_ERR_ARG, "the text path does not take plans that demultiplex barcodes with m + k > %d", CS_DEMUX_MAX_PREFIX);
   if (!n_slots || !max_records || !max_text_bytes) return fail(CS_ERR_ARG, "slots, records and text bytes must be positive");
   if (stride == 0 || stride % 4 || stride > CS_MAX_STRIDE)
     return fail(CS_ERR_ARG, "stride %u must be a multiple of 4 in [4, %d]", stride, CS_MAX_STRIDE);

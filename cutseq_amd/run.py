@@ -325,9 +325,7 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
               "CUTSEQ_DEVICES=0,0,... lists the GPUs to use, one entry per rank or worker, repeats allowed).")
     # Text path (default): the device parses the records and formats the output (textio.py / cs_text_*); the host
     # path below (native parser / formatter in a thread pool) stays for demultiplexing runs and as CUTSEQ_TEXT_PATH=0.
-    # (demultiplexing on long barcodes -- the op's "own ops" form -- stays on the round-2 host path: the text engine
-    # knows the table form only)
-    if (tp.demux is None or tp.demux.tabulated) and os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
+    if os.environ.get("CUTSEQ_TEXT_PATH", "1") != "0":
         from . import textio
         return textio.run_text_pipeline(args, tp, devices, _block_records(args, len(devices)),
                                         shares=shares)

@@ -210,25 +210,27 @@ def test_device_compressed_output_is_gzip_of_the_same_text(n):
         assert ratio > 2.5, ratio  # Huffman-only: ~2 bits per base / quality value, headers a little over 4
 
 
-@pytest.mark.parametrize("compress,paired", [(False, True), (True, True), (False, False)])
-def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired):
+@pytest.mark.parametrize("compress,paired,length,short_rows", [(False, True, 8, False), (True, True, 8, False), (False, False, 8, False),
+                                                              (False, True, 12, False), (True, True, 8, True), (False, True, 12, True)])
+def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired, length, short_rows):
     """cs_text_params.n_bins: the trimmed records of barcode b leave the device as route 3 + b (plain text or one gzip
     member per route), in input order; short and untrimmed pairs keep routes 1 and 2.  Expected: the array API's
     results and barcode indices for the same reads (held to the oracle by tests/test_gpu_demux.py), formatted by the
-    record logic."""
+    record logic.  12-base barcodes: the op's other form (every read through the resolve kernel).  ``short_rows``: rows
+    of 64 bases for 150-base reads, so every read takes the long-read kernel, which knows both forms too."""
     import gzip
     import random
     from cutseq_amd import hostfmt
     from test_gpu_demux import barcode_set, plant_barcodes, scheme_with
     rng = random.Random(77)
-    codes = barcode_set(rng, 24, 8, 4)
+    codes = barcode_set(rng, 24, length, 4)
     st = planmod.CutadaptConfig()
     st.trim_polyA = True
     st.min_length = 40
     st.demux_barcodes = codes
-    n = 20_000
+    n = 3_000 if short_rows else 20_000
     batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=8, adapter_fraction=0.5, single_end=not paired)
-    plant_barcodes(rng, batch, codes, 8)
+    plant_barcodes(rng, batch, codes, length)
     tp = (planmod.compile_paired if paired else planmod.compile_single)(BarcodeConfig(scheme_with(codes[0])), st)
     names1 = [s.encode() for s in synth.headers(n, 1)]
     names2 = [s.encode() for s in synth.headers(n, 2)]
@@ -256,10 +258,10 @@ def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired):
         want[route][0] += rec1
         want[route][1] += rec2
         want_counts[route] += 1
-    assert sum(1 for c in want_counts[3:] if c) == len(codes) and want_counts[1] > 100 and want_counts[2] > 100
+    assert sum(1 for c in want_counts[3:] if c) == len(codes) and want_counts[1] > n // 200 and want_counts[2] > n // 200
     with TrimEngine(tp, device=0, slots=0) as eng:
-        with textpath.TextEngine(eng, slots=2, max_text_bytes=len(text1) + 1024, max_records=n, stride=batch.stride,
-                                 compress=compress, bins=len(codes)) as te:
+        with textpath.TextEngine(eng, slots=2, max_text_bytes=len(text1) + 1024, max_records=n,
+                                 stride=64 if short_rows else batch.stride, compress=compress, bins=len(codes)) as te:
             for _ in range(2):  # (a slot's second batch: the route block is reset)
                 got, counts = te.run(text1, n, text2)
                 assert counts == want_counts
