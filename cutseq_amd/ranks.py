@@ -177,6 +177,10 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
     want = os.environ.get("CUTSEQ_DEVICES")
     devices = [int(x) for x in want.split(",")] if want else list(range(world))
     groups = {"output_file": args.output_file, "short_file": args.short_file, "untrimmed_file": args.untrimmed_file}
+    for b, names in enumerate(getattr(args, "demux_files", None) or []):  # demultiplexing: a pair of files per barcode
+        groups[f"demux_files:{b}"] = names
+    if getattr(args, "demux_files", None):
+        groups["output_file"] = [None] * len(args.output_file)  # (nothing is written under the common trimmed names)
     work = tempfile.mkdtemp(prefix="cutseq_ranks_")
     children, specs = [], []
     child_argv = _strip_option(argv, "--ranks")
@@ -210,7 +214,8 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
             report.merge_totals(totals, part)
             stats += part["stats"]
             devs += part["devices"]
-        totals.update(stats=stats, devices=devs, bin_names=None, seconds=time.perf_counter() - t0, ranks=world)
+        bin_names = list(args.demux[0]) if getattr(args, "demux", None) else None
+        totals.update(stats=stats, devices=devs, bin_names=bin_names, seconds=time.perf_counter() - t0, ranks=world)
         return totals
     except BaseException:
         for c in children:

@@ -480,13 +480,16 @@ def run_cutseq(args, argv=None):
         from . import ranks
         spec = ranks.load_spec(args.rank_spec)
         for key, names in spec["outputs"].items():
-            setattr(args, key, names)
+            if key.startswith("demux_files:"):
+                args.demux_files[int(key.split(":")[1])] = names
+            else:
+                setattr(args, key, names)
         totals = run_pipeline(args, tp, shares=spec["inputs"])
         ranks.dump_totals(spec, totals)
         return totals
     if getattr(args, "ranks", 1) > 1:
-        if tp.demux is not None or os.environ.get("CUTSEQ_TEXT_PATH", "1") == "0":
-            logging.warning("--ranks ignored: it needs the text path without demultiplexing.")
+        if os.environ.get("CUTSEQ_TEXT_PATH", "1") == "0":
+            logging.warning("--ranks ignored: it needs the text path.")
         else:
             from . import ranks
             totals = ranks.run_parent(list(sys.argv[1:] if argv is None else argv), args, tp)

@@ -236,3 +236,44 @@ def test_cli_demultiplexes_like_independent_runs(tmp_path, monkeypatch):
     assert sum(rep["engine"]["demultiplexed"].values()) == total_trimmed == rep["read_counts"]["output"]
     assert got_untr.count(b"\n") // 4 == n - total_trimmed - rep["read_counts"]["filtered"]["too_short"]
     assert zlib.crc32(got_untr) != 0 and len(unassigned) >= got_untr.count(b"\n") // 4
+
+
+def test_cli_demultiplexes_under_ranks_like_one_process(tmp_path, monkeypatch):
+    """--ranks 2 with --demux-barcodes: every rank writes a part of every barcode's files, the parent concatenates them
+    in rank order -- same bytes (decompressed) and same report as the one-process run."""
+    import gzip
+    import json
+
+    from cutseq_amd import run as cli
+
+    rng = random.Random(12)
+    length, count, n = 8, 12, 30_000
+    codes = barcode_set(rng, count, length, 5)
+    names = [f"bc{i:02d}" for i in range(count)]
+    batch = synth.generate_pairs(n, 150, scheme_with(codes[0]), seed=22)
+    plant_barcodes(rng, batch, codes, length)
+    names1 = [f"SIM:{i} 1:N:0:X".encode() for i in range(n)]
+    names2 = [f"SIM:{i} 2:N:0:X".encode() for i in range(n)]
+    in1, in2 = str(tmp_path / "d_R1.fastq"), str(tmp_path / "d_R2.fastq.gz")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=4000)
+    table = tmp_path / "barcodes.tsv"
+    table.write_text("".join(f"{a}\t{b}\n" for a, b in zip(names, codes)))
+    monkeypatch.setenv("CUTSEQ_CHUNK_READS", "5000")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    common = ["-a", scheme_with(codes[0]), "--demux-barcodes", str(table)]
+    cli.main(common + ["-O", one, "--json-file", str(tmp_path / "one.json"), in1, in2])
+    monkeypatch.setenv("CUTSEQ_DEVICES", "0,0")
+    cli.main(common + ["-O", two, "--json-file", str(tmp_path / "two.json"), "--ranks", "2", in1, in2])
+
+    def gunzip(path):
+        with gzip.open(path, "rb") as fh:
+            return fh.read()
+
+    kinds = [f"{name}_trimmed" for name in names] + ["short", "untrimmed"]
+    for kind in kinds:
+        for mate in (1, 2):
+            assert gunzip(f"{two}_{kind}_R{mate}.fastq.gz") == gunzip(f"{one}_{kind}_R{mate}.fastq.gz"), (kind, mate)
+    a, b = json.loads((tmp_path / "one.json").read_text()), json.loads((tmp_path / "two.json").read_text())
+    assert a["read_counts"] == b["read_counts"] and a["engine"]["demultiplexed"] == b["engine"]["demultiplexed"]
+    assert sum(b["engine"]["demultiplexed"].values()) > n // 2 and not list(tmp_path.glob("*.part*"))
