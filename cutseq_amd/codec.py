@@ -356,10 +356,13 @@ class GzipSource:
                 if buf[head] == 0 and not any(buf[head:min(n, head + (1 << 20))]):
                     return  # zero padding after the last member (tar-style): done
                 submit(head)
-                while len(cands) < window and scan_from < n:
-                    p = buf.find(b"\x1f\x8b\x08", scan_from)
+                # (member starts are looked for in the next 64 MB of compressed bytes only: mmap.find holds the GIL, and on
+                # one huge member -- no magic anywhere -- it would walk the whole file while every other thread waits)
+                ahead = min(n, head + _MEMBER_CAP // 4 + 2)
+                while len(cands) < window and scan_from < ahead:
+                    p = buf.find(b"\x1f\x8b\x08", scan_from, ahead)
                     if p < 0:
-                        scan_from = n
+                        scan_from = max(scan_from, ahead - 2)
                         break
                     scan_from = p + 1
                     if p + 18 <= n and (buf[p + 3] & 0xE0) == 0:

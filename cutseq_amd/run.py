@@ -309,6 +309,7 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
     from . import capi, fastq
 
     n_dev = capi.device_count()
+    _phase("devices counted")
     if n_dev <= 0:
         raise capi.HipUnavailable("no HIP device visible; cutseq_amd has no CPU trimming path")
     if getattr(args, "threads", None) is not None:

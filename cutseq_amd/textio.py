@@ -597,6 +597,9 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
     opened: List[StreamWriter] = []
     try:
         r2 = TextReader(in2, chunk_reads, **share[1]) if paired else None
+        if PROFILE:
+            from .run import _phase
+            _phase("readers started")
 
         # every output a ".gz" file: the device compresses (deflate_kernels.hip.inc) and the writers pass the members
         # through; otherwise text comes back and ".gz" outputs are deflated in the host pool (CUTSEQ_GPU_DEFLATE=0 too)
