@@ -65,9 +65,9 @@ def main():
     run("gz_to_gz", gz_in, ["-O", str(work / "gzout")])
     run("gz_to_gz_warm", gz_in, ["-O", str(work / "gzout")])
     run("plain_to_gz", plain_in, ["-O", str(work / "gzout")])
-    # the usual sequencer output: ONE gzip member per file (gzip -1 of the first quarter of the records), which no
+    # the usual sequencer output: ONE gzip member per file (gzip -1 of the first half of the records), which no
     # reader can enter in the middle
-    n_single = n // 4
+    n_single = n // 2
     t0 = time.perf_counter()
     procs = []
     for m in (1, 2):
