@@ -58,7 +58,7 @@ import torch  # noqa: E402
 from cutseq_amd import abi, shard, workloads  # noqa: E402
 from cutseq_amd.build import kernel_source_hash  # noqa: E402
 from cutseq_amd.engine import TrimEngine  # noqa: E402
-from cutseq_amd.workloads import CONFIG4_SCHEME, READ_LEN  # noqa: E402
+from cutseq_amd.workloads import READ_LEN  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)

@@ -17,7 +17,6 @@ A gzip input that is one single member cannot be entered in the middle: such a r
 """
 from __future__ import annotations
 
-import ctypes as C
 import json
 import logging
 import os

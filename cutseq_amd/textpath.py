@@ -9,7 +9,7 @@ records of the three routes; the host reads / inflates and deflates / writes, no
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 

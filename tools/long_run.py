@@ -3,7 +3,6 @@
 the peak resident set and the arena's footprint at the end -- leaks and slow-downs show here, not in 8 M pairs.
     python3 tools/long_run.py [pairs]"""
 import json
-import os
 import resource
 import shutil
 import subprocess

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Write a synthetic paired FASTQ data set (gz) with the seeded generator: tools/make_fastq.py N out_prefix"""
 import sys
-import zlib
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
