@@ -349,7 +349,13 @@ def _fallocate(fd: int, offset: int, length: int) -> bool:
             _libc = False
     if not _libc:
         return False
-    return _libc.fallocate(fd, 0, offset, length) == 0
+    if _libc.fallocate(fd, 0, offset, length) == 0:
+        return True
+    err = C.get_errno()
+    import errno
+    if err in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL, errno.ENODEV, errno.ESPIPE):
+        return False  # this file (system) cannot do it: the caller truncates instead
+    raise OSError(err, os.strerror(err))  # disk full, file too large, ...: better here than as SIGBUS in a mapping
 
 
 class StreamWriter:
@@ -364,6 +370,7 @@ class StreamWriter:
         self.fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
         self.pos = 0
         self.mappable = not self.gz  # (gzip members are small: plain pwrite, the pool has better things to do)
+        self._can_allocate = True    # plain output: fallocate works on this file (system)
         self.q: "queue.Queue" = queue.Queue()
         self.err: Optional[BaseException] = None
         self.t = threading.Thread(target=self._run, daemon=True, name=f"cutseq-write-{os.path.basename(path)}")
@@ -402,8 +409,10 @@ class StreamWriter:
     def _copy_mapped(self, mv: memoryview, n: int) -> None:
         start, end = self.pos, self.pos + n
         # the new range gets its pages in ONE call where the file system can do that (tmpfs, ext4, xfs: 18 GB/s on the
-        # GPU box against 4-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write.py)
-        if not _fallocate(self.fd, start, n):
+        # GPU box against 4-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write.py).
+        # (Allocating the NEXT range in the pool meanwhile was tried: no faster, the call competes with the copies.)
+        if not (self._can_allocate and _fallocate(self.fd, start, n)):
+            self._can_allocate = False
             os.ftruncate(self.fd, end)
         base = start - start % _PAGE
         mm = mmap.mmap(self.fd, end - base, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE, offset=base)

@@ -21,6 +21,9 @@ sys.path.insert(0, str(ROOT))
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+    # the steady-state regime: blocks of 262 144 records, what inputs of 25 M pairs and more get (smaller inputs get
+    # smaller blocks -- a fresh process spends more time page-locking big buffers than it saves: tools/cold_runs.py)
+    os.environ.setdefault("CUTSEQ_CHUNK_READS", "262144")
     work = Path(sys.argv[2] if len(sys.argv) > 2 else "/dev/shm/cutseq_e2e")
     work.mkdir(parents=True, exist_ok=True)
     free = shutil.disk_usage(work).free

@@ -13,6 +13,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 os.environ["CUTSEQ_PROFILE"] = "1"
+os.environ.setdefault("CUTSEQ_CHUNK_READS", "262144")  # the steady-state regime (see tools/e2e_bench.py)
 
 
 def main():
