@@ -16,7 +16,7 @@ LIB_PATH = Path(__file__).with_name("libcutseq_hip.so")
 EXPORTS = (
     "cs_abi_version", "cs_last_error", "cs_device_count", "cs_plan_create", "cs_plan_destroy", "cs_plan_set_demux", "cs_plan_set_demux_ops",
     "cs_engine_create", "cs_engine_destroy", "cs_trim_device", "cs_trim_device_pipelined", "cs_join", "cs_trim_batch", "cs_sync",
-    "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_kernel_time_totals", "cs_alloc_pinned", "cs_free_pinned", "cs_alloc_device",
+    "cs_stats_fetch", "cs_last_kernel_ms", "cs_last_kernel_split_ms", "cs_kernel_time_totals", "cs_alloc_pinned", "cs_alloc_pinned_huge", "cs_free_pinned", "cs_alloc_device",
     "cs_free_device", "cs_copy_to_device", "cs_copy_to_host",
     "cs_text_create", "cs_text_destroy", "cs_text_submit", "cs_text_wait", "cs_text_routes", "cs_text_fetch",
 )
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     L.cs_kernel_time_totals.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float * 2), i32]
     L.cs_alloc_pinned.restype = vp
     L.cs_alloc_pinned.argtypes = [C.c_size_t]
+    L.cs_alloc_pinned_huge.restype = vp
+    L.cs_alloc_pinned_huge.argtypes = [C.c_size_t]
     L.cs_free_pinned.restype = None
     L.cs_free_pinned.argtypes = [vp]
     L.cs_alloc_device.restype = vp

@@ -512,10 +512,10 @@ def run_cutseq(args, argv=None):
 
 def _block_records(args, n_devices: int) -> int:
     """Records per block of the text path: ``CUTSEQ_CHUNK_READS`` if set, else 262 144 -- less for small inputs, so
-    that a short run does not page-lock and allocate for blocks it never fills (a 2 M-pair run spends more time
-    setting up and tearing down a gigabyte of buffers than trimming; 8 M pairs of plain text as a fresh process, in and
-    out: 2.05 s with blocks of 262 144 records, 1.45 s with 131 072, 1.11 s with 65 536 -- tools/cold_runs.py): about a
-    hundred blocks per device."""
+    that a short run does not allocate (and page-lock) for blocks it never fills: about two dozen blocks per device.
+    (With the block buffers on huge pages the size matters little for a fresh 8 M-pair process -- 0.83 to 0.90 s for
+    plain text with blocks of 65 536 to 262 144 records, and gzip input likes the big ones: 1.33 against 1.51 s;
+    profiles/r03_cold_runs.log.)"""
     from . import textio
     if os.environ.get("CUTSEQ_CHUNK_READS"):
         return int(os.environ["CUTSEQ_CHUNK_READS"])
@@ -526,7 +526,7 @@ def _block_records(args, n_devices: int) -> int:
     if args.input_file[0].endswith(".gz"):
         size *= 4  # (a guess at the text behind it)
     records = size // 300  # (a short-read record is ~330 bytes)
-    want = records // (96 * max(n_devices, 1))
+    want = records // (24 * max(n_devices, 1))
     block = textio.CHUNK_READS
     while block > 16384 and block > want:
         block //= 2
