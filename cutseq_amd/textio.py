@@ -564,6 +564,12 @@ class TextWorker(threading.Thread):
     def run(self):
         inflight: deque = deque()
         try:
+            # the trimming engine right away (plan upload, code object load: 0.1-0.2 s), while the readers are still
+            # getting their first blocks; the text engine follows when the first block says how big it has to be
+            t0 = time.perf_counter()
+            from .engine import TrimEngine
+            self.engine = TrimEngine(self.tp, device=self.device, slots=0)
+            _tick("ensure", t0)
             while True:
                 t0 = time.perf_counter()
                 item = self.inbox.get()
