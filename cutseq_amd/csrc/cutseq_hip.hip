@@ -228,7 +228,8 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
         return fail(CS_ERR_ARG, "mate %d op %d: demux barcode length %u with %u errors (m + k <= %d)", mate, index, op.m,
                     op.k, CS_DEMUX_MAX_LONG);
       // filter_mode of a demultiplexing op: 0 = table look-up, 1 = the barcodes' own ops (cs_plan_set_demux_ops)
-      out.filter_mode = (op.m + op.k > CS_DEMUX_MAX_PREFIX || op.shortcut == CS_DEMUX_BY_OPS) ? 1u : 0u;
+      // (barcodes at the 3' end -- cs_op.reversed, SuffixAdapter ops -- exist in the second form only)
+      out.filter_mode = (op.m + op.k > CS_DEMUX_MAX_PREFIX || op.shortcut == CS_DEMUX_BY_OPS || op.reversed) ? 1u : 0u;
       break;
     default:
       return fail(CS_ERR_ARG, "mate %d op %d: unknown op kind %u", mate, index, op.kind);
@@ -643,13 +644,17 @@ int cs_plan_set_demux_ops(cs_plan *plan, int mate, int op_index, const cs_op *op
     std::vector<std::string> digits;
     for (int b = 0; b < n_ops; ++b) {
       const cs_op &in = ops[b];
-      if (in.kind != CS_OP_ADAPTER || in.align_flags != CS_WHERE_PREFIX || in.reversed || in.remove != CS_REMOVE_BEFORE ||
-          in.shortcut != CS_SHORTCUT_NONE || in.m != op.m || in.k != op.k || in.min_overlap != in.m)
-        return fail(CS_ERR_ARG, "barcode %d: not the PrefixAdapter op of a %u-base barcode with %u errors", b, op.m, op.k);
+      const bool at_end = op.reversed != 0;  // barcodes at the 3' end: SuffixAdapter ops, the table walks the read backwards
+      if (in.kind != CS_OP_ADAPTER || in.align_flags != (at_end ? CS_WHERE_SUFFIX : CS_WHERE_PREFIX) || in.reversed ||
+          in.remove != (at_end ? CS_REMOVE_AFTER : CS_REMOVE_BEFORE) || in.shortcut != CS_SHORTCUT_NONE || in.m != op.m ||
+          in.k != op.k || in.min_overlap != in.m)
+        return fail(CS_ERR_ARG, "barcode %d: not the %s op of a %u-base barcode with %u errors", b,
+                    at_end ? "SuffixAdapter" : "PrefixAdapter", op.m, op.k);
       std::string dg;
       for (int i = 0; i < in.m; ++i) {
-        if (!is_acgt(in.seq[i])) return fail(CS_ERR_ARG, "barcode %d: bases other than A, C, G, T", b);
-        dg.push_back((char)((in.seq[i] >> 1) & 3));
+        const uint8_t c = in.seq[at_end ? in.m - 1 - i : i];
+        if (!is_acgt(c)) return fail(CS_ERR_ARG, "barcode %d: bases other than A, C, G, T", b);
+        dg.push_back((char)((c >> 1) & 3));
       }
       digits.push_back(dg);
       csdev::DevOp d;

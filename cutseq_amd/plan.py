@@ -141,6 +141,7 @@ class DemuxOp:
     required: bool = True
     table: Optional[object] = None  # numpy uint16 array once built
     by_ops: bool = False  # the barcodes' own ops even where a table would fit (how the tables themselves are built)
+    at_end: bool = False  # the barcodes sit at the 3' end of the read (SuffixAdapter ops; second form only)
 
     def __post_init__(self):
         self.barcodes = [b.upper().replace("U", "T") for b in self.barcodes]
@@ -167,11 +168,12 @@ class DemuxOp:
     def tabulated(self) -> bool:
         """True: the op is a look-up table over every prefix of m + k bases (cs_plan_set_demux); False: longer
         barcodes, the op carries one PrefixAdapter op per barcode (cs_plan_set_demux_ops)."""
-        return self.m + self.k <= abi.CS_DEMUX_MAX_PREFIX and not self.by_ops
+        return self.m + self.k <= abi.CS_DEMUX_MAX_PREFIX and not self.by_ops and not self.at_end
 
     def barcode_ops(self):
         """The barcodes' own adapter ops, as single-barcode plans hold them (cutseq/run.py:357-362, 592-597)."""
-        return [prefix(code, self.max_error_rate, self.match_flag, required=self.required) for code in self.barcodes]
+        make = suffix if self.at_end else prefix
+        return [make(code, self.max_error_rate, self.match_flag, required=self.required) for code in self.barcodes]
 
     def __repr__(self):
         return (f"Demultiplexer({len(self.barcodes)} x PrefixAdapter(length={self.m}, "
@@ -285,6 +287,7 @@ def pack_ops(ops: Sequence[Op], limit: int = abi.CS_MAX_OPS):
         elif isinstance(op, DemuxOp):
             c.kind = abi.CS_OP_DEMUX
             c.shortcut = abi.CS_DEMUX_BY_OPS if op.by_ops else 0
+            c.reversed = 1 if op.at_end else 0
             c.m, c.k = op.m, op.k
             c.match_flag = op.match_flag
             c.required = 1 if op.required else 0
@@ -349,13 +352,12 @@ def _demux_op(barcode: BarcodeConfig, settings, paired: bool):
     if barcode.inline5.len == 0 and barcode.inline3.len == 0:
         raise ValueError("demultiplexing needs a scheme with an inline barcode, e.g. P5(ATCACG)NNNN>P7")
     at5 = barcode.inline5.len > 0
-    if not at5 and not paired:
-        raise ValueError("demultiplexing on the 3' inline barcode needs paired reads (it is the start of R2)")
     inline = barcode.inline5 if at5 else barcode.inline3
-    if not at5:
+    if not at5 and paired:
         from .common import reverse_complement
         codes = [reverse_complement(c.upper().replace("U", "T")) for c in codes]
-    op = DemuxOp(list(codes), MAX_ERRORS, abi.CS_F_INLINE, required=True)
+    # (single-end reads and a 3' barcode: it ends the read once the 3' adapter is gone -- SuffixAdapter ops, run.py:364-370)
+    op = DemuxOp(list(codes), MAX_ERRORS, abi.CS_F_INLINE, required=True, at_end=not at5 and not paired)
     if op.m != inline.len:
         raise ValueError(f"the barcodes are {op.m} nt long, the scheme's inline barcode {inline.len}")
     return (op, None) if at5 else (None, op)
@@ -372,14 +374,16 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     ops.append(rightmost_front(barcode.p5.fw, MAX_ERRORS, 10, abi.CS_F_ADAPTER5, sc))
     ops.append(back(barcode.p7.fw, MAX_ERRORS, 3, settings.force_anywhere, abi.CS_F_ADAPTER3, sc))
     # step 4: inline barcodes
-    demux, _ = _demux_op(barcode, settings, paired=False)
-    if demux is not None:
+    demux, demux3 = _demux_op(barcode, settings, paired=False)
+    if demux is not None or demux3 is not None:
         untrimmed_filter = True  # a read without any of the barcodes goes where --ensure-inline-barcode sends it
+    if demux is not None:
         ops.append(demux)
     elif barcode.inline5.len > 0:
         ops.append(prefix(barcode.inline5.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
     if barcode.inline3.len > 0:
-        ops.append(suffix(barcode.inline3.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
+        ops.append(demux3 if demux3 is not None else
+                   suffix(barcode.inline3.fw, MAX_ERRORS, abi.CS_F_INLINE, required=untrimmed_filter))
     # step 5: UMI (always unconditional in single-end mode), then rename
     cap = 0
     if barcode.umi5.len > 0:

@@ -115,7 +115,9 @@ typedef struct cs_op {
   uint8_t kind;          /* CS_OP_*                                                   */
   uint8_t align_flags;   /* ADAPTER: CS_WHERE_*                                       */
   uint8_t reversed;      /* ADAPTER: 1 = RightmostFrontAdapter: `seq` holds the reversed
-                            adapter, the aligner walks the read right-to-left        */
+                            adapter, the aligner walks the read right-to-left;
+                            DEMUX: 1 = the barcodes end the read (SuffixAdapter ops through
+                            cs_plan_set_demux_ops: CS_WHERE_SUFFIX, CS_REMOVE_AFTER)     */
   uint8_t remove;        /* ADAPTER: CS_REMOVE_BEFORE (read[rstop:]) / _AFTER (read[:rstart]) */
   uint8_t shortcut;      /* ADAPTER: CS_SHORTCUT_*; DEMUX: CS_DEMUX_BY_OPS = the barcodes' own ops even where a table would fit */
   uint8_t match_flag;    /* ADAPTER: CS_F_* bit OR-ed into the result when it matched */

@@ -139,8 +139,17 @@ def test_long_barcodes_take_their_own_ops_not_a_table(lib):
     only3 = "ACACGACGCTCTTCCGATCTNNNNNNNN>(ACGTACGTAC)AGATCGGAAGAGCACACGTC"
     tp = planmod.compile_paired(BarcodeConfig(only3), st)
     assert tp.demux_mate == 2 and tp.demux.barcodes == ["GTACGTACGT", "TTGCATGCAA"]  # as R2 reads them
-    with pytest.raises(ValueError):
-        planmod.compile_single(BarcodeConfig(only3), st)
+    se = planmod.compile_single(BarcodeConfig(only3), st)  # single-end: the barcode ends the read (SuffixAdapter ops)
+    assert se.demux.at_end and not se.demux.tabulated and se.demux.barcodes == ["ACGTACGTAC", "TTGCATGCAA"]
+    rc, h = _create(lib, se)
+    assert rc == 0
+    index = next(i for m, i, _ in se.demux_ops())
+    ops = planmod.pack_ops(se.demux.barcode_ops(), limit=255)
+    assert ops[0].align_flags == abi.CS_WHERE_SUFFIX
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 2) == 0, lib.cs_last_error()
+    ops[0].align_flags = abi.CS_WHERE_PREFIX
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 2) == abi.CS_ERR_ARG
+    lib.cs_plan_destroy(h)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="GPU present: covered by the gpu suite")

@@ -158,6 +158,78 @@ def test_demux_on_the_3prime_barcode_at_the_start_of_r2(length, count):
     assert np.array_equal(g1, pick([o1 for o1, _ in runs]))
 
 
+@pytest.mark.parametrize("length,count,text", [(8, 12, False), (12, 16, False), (8, 12, True)])
+def test_demux_on_the_3prime_barcode_of_single_end_reads(length, count, text):
+    """Single-end reads of a scheme whose only inline barcode sits at the 3' end: once the 3' adapter is gone the
+    barcode ENDS the read -- one SuffixAdapter per barcode in the reference's terms (cutseq/run.py:364-370).  The op
+    runs the candidates' own suffix ops (the candidate table walks the read backwards).  Parity: one
+    --ensure-inline-barcode run per barcode; ``text``: through the text path, one route per barcode."""
+    def scheme3(code):
+        return f"ACACGACGCTCTTCCGATCTNNNNNNNN>({code})AGATCGGAAGAGCACACGTC"
+
+    rng = random.Random(length * 7 + count)
+    codes = barcode_set(rng, count, length, 4)
+    st = planmod.CutadaptConfig()
+    st.ensure_inline_barcode = True
+    per = 400
+    parts = [synth.generate_pairs(per, 150, scheme3(code), seed=length + i, single_end=True, adapter_fraction=0.7)
+             for i, code in enumerate(codes)]
+    parts.append(synth.generate_pairs(per, 150, scheme3(util.random_dna(rng, length)), seed=99, single_end=True))  # foreign
+    order = np.random.default_rng(3).permutation(per * len(parts))
+    batch = synth.SynthBatch(np.ascontiguousarray(np.vstack([p.seq1 for p in parts])[order]),
+                             np.ascontiguousarray(np.vstack([p.qual1 for p in parts])[order]),
+                             np.ascontiguousarray(np.concatenate([p.len1 for p in parts])[order]), None, None, None)
+    n = batch.n
+    st.demux_barcodes = codes
+    tp = planmod.compile_single(BarcodeConfig(scheme3(codes[0])), st)
+    assert tp.demux.at_end and not tp.demux.tabulated
+    st.demux_barcodes = None
+    runs = []
+    for code in codes:
+        one = planmod.compile_single(BarcodeConfig(scheme3(code)), st)
+        (o1, _, _), _ = util.oracle_run(one, batch, threads=8)
+        runs.append(o1)
+    matched = np.stack([(o["flags"] & abi.CS_F_INLINE) != 0 for o in runs])
+    assert 0.3 < float(matched.any(axis=0).mean()) < 0.95  # (reads without read-through have no barcode at their end)
+    want_bc = np.where(matched.any(axis=0), matched.argmax(axis=0), abi.CS_DEMUX_NONE).astype(np.uint8)
+    if not text:
+        bc = np.empty(n, dtype=np.uint8)
+        with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
+            g1, _, _ = eng.submit(0, batch.seq1, batch.qual1, batch.len1, bc=bc)
+            eng.wait(0)
+        amb = (g1["flags"] & abi.CS_F_AMBIGUOUS) != 0
+        assert np.array_equal(matched.sum(axis=0) > 1, amb)
+        assert np.array_equal(bc[~amb], want_bc[~amb])
+        own = np.where(bc == abi.CS_DEMUX_NONE, 0, bc).astype(np.int64)
+        want1 = np.stack(runs)[own, np.arange(n)]
+        want1["flags"] |= np.where(amb, abi.CS_F_AMBIGUOUS, 0).astype(np.uint8)
+        assert np.array_equal(g1, want1)
+        return
+    from cutseq_amd import hostfmt, textpath
+    names = [f"SE:{i} 1:N:0:X".encode() for i in range(n)]
+    text1 = b"".join(b"@" + names[i] + b"\n" + batch.seq1[i, :batch.len1[i]].tobytes() + b"\n+\n" +
+                     batch.qual1[i, :batch.len1[i]].tobytes() + b"\n" for i in range(n))
+    amb_any = matched.sum(axis=0) > 1
+    want = [b""] * (3 + count)
+    want_counts = [0] * (3 + count)
+    for i in range(n):
+        if amb_any[i]:
+            continue
+        own = int(want_bc[i]) if want_bc[i] != abi.CS_DEMUX_NONE else 0
+        ln = int(batch.len1[i])
+        route, rec = hostfmt.format_single(names[i], batch.seq1[i, :ln].tobytes(), batch.qual1[i, :ln].tobytes(), runs[own][i], None, tp)
+        want[3 + own if route == 0 else route] += rec
+        want_counts[3 + own if route == 0 else route] += 1
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=1, max_text_bytes=len(text1) + 1024, max_records=n, stride=batch.stride, bins=count) as te:
+            got, counts = te.run(text1, n)
+    assert sum(counts) == n and sum(counts[3:]) > n // 4
+    if not amb_any.any():
+        assert counts == want_counts
+        for route in range(3 + count):
+            assert got[route][0] == want[route], route
+
+
 def test_demux_table_matches_the_oracle_on_every_prefix():
     """The device-built table against the CPU oracle's PrefixAdapter on all 5^0 + ... + 5^(m+k) prefixes."""
     rng = random.Random(3)
