@@ -24,7 +24,77 @@ from cutseq_amd.engine import TrimEngine  # noqa: E402
 from test_oracle import CHAIN_CASES  # noqa: E402
 
 
+def bins_case(seed: int) -> None:
+    """One demultiplexing batch through the text path (one route per barcode), expected from the array API's results and
+    barcode indices (held to the oracle by tests/test_gpu_demux.py) formatted by the record logic."""
+    from cutseq_amd import abi, hostfmt
+    from cutseq_amd.common import BarcodeConfig
+    from test_gpu_demux import barcode_set, plant_barcodes, scheme_with
+    rng = random.Random(seed)
+    length = rng.choice([6, 8, 8, 10, 12])
+    count = rng.choice([2, 5, 24, 60])
+    paired = rng.random() < 0.7
+    compress = rng.random() < 0.4
+    codes = barcode_set(rng, count, length, 3 if length <= 6 else 4)
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = rng.random() < 0.5
+    st.min_length = rng.choice([20, 40])
+    st.demux_barcodes = codes
+    n = rng.choice([1, 64, 257, 1000, 9000])
+    batch = synth.generate_pairs(n, rng.choice([100, 150]), scheme_with(codes[0]), seed=seed, adapter_fraction=0.5, single_end=not paired)
+    plant_barcodes(rng, batch, codes, length)
+    tp = (planmod.compile_paired if paired else planmod.compile_single)(BarcodeConfig(scheme_with(codes[0])), st)
+    names1 = [f"B{seed}:{i} 1:N:0:X".encode() for i in range(n)]
+    names2 = [f"B{seed}:{i} 2:N:0:X".encode() for i in range(n)]
+    text1 = tt.fastq_text(names1, batch.seq1, batch.qual1, batch.len1)
+    text2 = tt.fastq_text(names2, batch.seq2, batch.qual2, batch.len2) if paired else None
+    bc = np.empty(n, dtype=np.uint8)
+    with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
+        r1, cap2, r2 = eng.submit(0, batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2, bc=bc)
+        eng.wait(0)
+    want = [[b"", b""] for _ in range(3 + count)]
+    want_counts = [0] * (3 + count)
+    for i in range(n):
+        n1 = int(batch.len1[i])
+        if paired:
+            n2 = int(batch.len2[i])
+            route, rec1, rec2 = hostfmt.format_pair(names1[i], batch.seq1[i, :n1].tobytes(), batch.qual1[i, :n1].tobytes(), r1[i],
+                                                    names2[i], batch.seq2[i, :n2].tobytes(), batch.qual2[i, :n2].tobytes(), r2[i], tp)
+        else:
+            route, rec1 = hostfmt.format_single(names1[i], batch.seq1[i, :n1].tobytes(), batch.qual1[i, :n1].tobytes(), r1[i],
+                                                cap2[i] if cap2 is not None else None, tp)
+            rec2 = b""
+        if route == 0:
+            assert bc[i] != abi.CS_DEMUX_NONE, seed
+            route = 3 + int(bc[i])
+        want[route][0] += rec1
+        want[route][1] += rec2
+        want_counts[route] += 1
+    short_rows = rng.random() < 0.15 and n <= 1000
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=2, max_text_bytes=max(len(text1), len(text2 or b"")) + 1024, max_records=n,
+                                 stride=64 if short_rows else batch.stride, compress=compress, bins=count) as te:
+            got, counts = te.run(text1, n, text2, slot=rng.randrange(2))
+    assert counts == want_counts, (seed, counts, want_counts)
+    for route in range(3 + count):
+        for m in range(2 if paired else 1):
+            data = got[route][m]
+            if compress and data:
+                data = gzip.decompress(data)
+            assert data == want[route][m], (seed, route, m)
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "bins":  # python tests/soak_text.py seconds first_seed bins
+        budget, seed, t0, done = float(sys.argv[1]), int(sys.argv[2]), time.time(), 0
+        while time.time() - t0 < budget:
+            bins_case(seed)
+            seed += 1
+            done += 1
+            if done % 25 == 0:
+                print(f"{time.time() - t0:6.0f} s  seed {seed}  demultiplexing batches {done}", flush=True)
+        print(f"text soak (bins) ok: {done} batches, seeds up to {seed}, {time.time() - t0:.0f} s")
+        return
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000
     cases = [c for c in CHAIN_CASES if "shortcut" not in c[1]]
