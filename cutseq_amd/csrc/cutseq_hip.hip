@@ -8,9 +8,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/mman.h>
@@ -578,54 +580,135 @@ namespace {
 // row was <= k at an earlier column (a match that ends inside the prefix).  k = thr[m] bounds every length's
 // threshold, so the lists are supersets of the barcodes whose PrefixAdapter matches; the device runs those ops
 // themselves on the candidates (trim_kernel.hip.inc, CS_OP_DEMUX).
+// The walk is cut at depth 2: the subtrees below are independent and go to a few threads; every piece of the
+// pre-order (the top of the tree between two subtrees, a subtree) writes a SEGMENT of its own, and the segments are
+// laid into the table in pre-order afterwards -- the same table as a serial walk, whatever the thread count.
+struct DemuxSegment {
+  std::vector<uint8_t> pool;                          // candidate lists of this piece
+  std::vector<std::pair<size_t, uint32_t>> first;     // (table slot, offset into `pool` << 8 | candidates)
+};
+
 struct DemuxWalk {
   const std::vector<std::string> &digits;  // per barcode: its bases as digits 0..3
   int m, k, depth;
-  DemuxLong &out;
-  std::vector<size_t> block;  // where the prefixes of each length start
-  bool overflow = false;
+  const std::vector<size_t> &block;  // where the prefixes of each length start
 
   struct Alive {
     int id;
     bool done;
     uint8_t col[CS_MAX_ADAPTER + 1];
   };
+  struct Task {
+    int len;
+    size_t idx, pw, segment;
+    std::vector<Alive> alive;
+  };
+  std::vector<std::vector<Alive>> scratch;  // walk(): the children's lists, one per depth
+  DemuxSegment *seg = nullptr;              // the piece being written
+  bool overflow = false;
+  // top of the tree only: where to cut, the pieces so far, the subtrees left to others
+  int split = -1;
+  std::vector<DemuxSegment> *segments = nullptr;
+  std::vector<Task> *tasks = nullptr;
 
   void emit(size_t at, const std::vector<Alive> &alive) {
     if (alive.empty()) return;
-    if (out.pool.size() + alive.size() >= (1u << 24) || alive.size() > 255) {
+    if (seg->pool.size() + alive.size() >= (1u << 24) || alive.size() > 255) {
       overflow = true;
       return;
     }
-    out.first[at] = (uint32_t)(out.pool.size() << 8) | (uint32_t)alive.size();
-    for (const Alive &a : alive) out.pool.push_back((uint8_t)a.id);
+    seg->first.emplace_back(at, (uint32_t)(seg->pool.size() << 8) | (uint32_t)alive.size());
+    for (const Alive &a : alive) seg->pool.push_back((uint8_t)a.id);
   }
 
   void walk(int len, size_t idx, size_t pw, const std::vector<Alive> &alive) {
+    if (len == split && len < depth) {  // a subtree for the threads: its segment keeps this place in the order
+      segments->emplace_back();
+      tasks->push_back(Task{len, idx, pw, segments->size() - 1, alive});
+      segments->emplace_back();  // the top of the tree goes on in a fresh piece behind it
+      seg = nullptr;             // (re-pointed by the caller: `segments` may have moved)
+      return;
+    }
+    if (!seg) seg = &segments->back();
     emit(block[len] + idx, alive);
     if (len == depth || overflow) return;
-    std::vector<Alive> next;
+    // (one list per depth, reused by every node of that depth: two million nodes would otherwise allocate one each)
+    if (scratch.size() <= (size_t)len) scratch.resize((size_t)depth + 1);
     for (int c = 0; c < 5; ++c) {
+      std::vector<Alive> &next = scratch[len];
       next.clear();
       for (const Alive &a : alive) {
-        Alive b;
+        next.emplace_back();
+        Alive &b = next.back();
         b.id = a.id;
-        const std::string &bc = digits[a.id];
+        if (a.done) {  // matched inside the prefix already: a candidate whatever follows, its column is not looked at again
+          b.done = true;
+          continue;
+        }
+        const char *bc = digits[a.id].data();
         const int cap = k + 1;  // costs are clamped there: nothing above k is ever told apart
+        // row i of the column behind len + 1 bases costs at least |i - (len + 1)| (the prefix is anchored): only the
+        // 2k + 1 rows around the diagonal can be below the cap, the others hold it
+        const int lo = std::max(1, len + 1 - k), hi = std::min(m, len + 1 + k);
+        memset(b.col, cap, (size_t)m + 1);
         int best = b.col[0] = (uint8_t)std::min(len + 1, cap);
-        for (int i = 1; i <= m; ++i) {
+        for (int i = lo; i <= hi; ++i) {
           const int sub = a.col[i - 1] + ((c < 4 && bc[i - 1] == c) ? 0 : 1);
           const int v = std::min(std::min(sub, std::min(a.col[i] + 1, b.col[i - 1] + 1)), cap);
           b.col[i] = (uint8_t)v;
           best = std::min(best, v);
         }
-        b.done = a.done || b.col[m] <= k;
-        if (b.done || best <= k) next.push_back(b);
+        b.done = b.col[m] <= k;
+        if (!b.done && best > k) next.pop_back();
       }
       if (!next.empty()) walk(len + 1, idx + (size_t)c * pw, pw * 5, next);
     }
   }
 };
+
+// the whole table: top of the tree here, subtrees on up to eight threads, segments merged in pre-order
+bool demux_walk_all(const std::vector<std::string> &digits, int m, int k, DemuxLong &dl, const std::vector<size_t> &block) {
+  const int n = (int)digits.size();
+  std::vector<DemuxWalk::Alive> all((size_t)n);
+  for (int b = 0; b < n; ++b) {
+    all[b].id = b;
+    all[b].done = false;
+    for (int i = 0; i <= m; ++i) all[b].col[i] = (uint8_t)std::min(i, k + 1);
+  }
+  std::vector<DemuxSegment> segments(1);
+  std::vector<DemuxWalk::Task> tasks;
+  DemuxWalk top{digits, m, k, dl.depth, block};
+  top.split = 2;
+  top.segments = &segments;
+  top.tasks = &tasks;
+  top.walk(0, 0, 1, all);
+  if (top.overflow) return false;
+  std::atomic<size_t> next_task{0};
+  std::atomic<bool> overflow{false};
+  auto worker = [&]() {
+    DemuxWalk w{digits, m, k, dl.depth, block};
+    for (size_t t; (t = next_task.fetch_add(1)) < tasks.size();) {
+      w.seg = &segments[tasks[t].segment];
+      w.walk(tasks[t].len, tasks[t].idx, tasks[t].pw, tasks[t].alive);
+      if (w.overflow) overflow = true;
+    }
+  };
+  unsigned n_threads = std::min<unsigned>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())), (unsigned)tasks.size());
+  if (const char *env = getenv("CUTSEQ_HOST_THREADS"))  // (the command line's -t/--threads, fastq.set_threads)
+    n_threads = std::max(1, std::min((int)n_threads, atoi(env)));
+  std::vector<std::thread> pool;
+  for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+  worker();
+  for (std::thread &t : pool) t.join();
+  if (overflow) return false;
+  for (const DemuxSegment &sg : segments) {
+    const size_t base = dl.pool.size();
+    if (base + sg.pool.size() >= (1u << 24)) return false;
+    for (const auto &f : sg.first) dl.first[f.first] = f.second + (uint32_t)(base << 8);
+    dl.pool.insert(dl.pool.end(), sg.pool.begin(), sg.pool.end());
+  }
+  return true;
+}
 
 }  // namespace
 
@@ -669,15 +752,8 @@ int cs_plan_set_demux_ops(cs_plan *plan, int mate, int op_index, const cs_op *op
     size_t pw = 1;
     for (int l = 0; l <= dl.depth; ++l, pw *= 5) block[l + 1] = block[l] + pw;
     dl.first.assign(block[dl.depth + 1], 0u);
-    DemuxWalk w{digits, (int)op.m, (int)op.k, dl.depth, dl, block};
-    std::vector<DemuxWalk::Alive> all(n_ops);
-    for (int b = 0; b < n_ops; ++b) {
-      all[b].id = b;
-      all[b].done = false;
-      for (int i = 0; i <= op.m; ++i) all[b].col[i] = (uint8_t)std::min(i, (int)op.k + 1);
-    }
-    w.walk(0, 0, 1, all);
-    if (w.overflow) return fail(CS_ERR_ARG, "demux: candidate lists exceed the table format");
+    if (!demux_walk_all(digits, (int)op.m, (int)op.k, dl, block))
+      return fail(CS_ERR_ARG, "demux: candidate lists exceed the table format");
     plan->demux_long[mate - 1][op_index] = std::move(dl);
   } catch (const std::bad_alloc &) {
     return fail(CS_ERR_NOMEM, "out of memory");

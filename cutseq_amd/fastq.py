@@ -606,6 +606,8 @@ def set_threads(n) -> None:
     if _POOL is not None and n != _THREADS:
         raise RuntimeError("the host pool is already running")
     _THREADS = None if n is None else max(1, int(n))
+    if _THREADS is not None:  # the library's own host threads (demultiplexing table build) honour the same bound
+        os.environ["CUTSEQ_HOST_THREADS"] = str(_THREADS)
 
 
 def pool_size() -> int:
