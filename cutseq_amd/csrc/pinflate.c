@@ -84,8 +84,10 @@ typedef struct {
   uint8_t len[288];              /* the code lengths the tables were built from */
   int n;
   /* literal / length codes only, built by huff_widen for the real decoder: one look-up tells literal, length (with
-   * its base and extra-bit count) and end of block apart.  [3:0] code length (0: longer than WIDE_BITS or no code),
-   * [5:4] 1 literal / 2 length / 3 end of block, [11:8] extra bits, [31:16] literal or length base (0: invalid). */
+   * its base and extra-bit count) and end of block apart.  [7:0] bits to consume in all, code + extra bits (0: a code
+   * longer than WIDE_BITS or none) -- the decoder shifts by the entry itself, the dependent chain from one look-up to
+   * the next is mask, load, shift --, [11:8] code length (where the extra bits start), [13:12] 1 literal / 2 length /
+   * 3 end of block, [31:16] literal or length base (0: invalid). */
   uint32_t wide[1 << WIDE_BITS];
 } huff_t;
 
@@ -151,18 +153,18 @@ static void huff_widen(huff_t *h) {
     for (int i = 0; i < l; ++i) r |= ((c >> i) & 1u) << (l - 1 - i);
     uint32_t e;
     if (s < 256)
-      e = ((uint32_t)s << 16) | 0x10u | (uint32_t)l;
+      e = ((uint32_t)s << 16) | 0x1000u | ((uint32_t)l << 8) | (uint32_t)l;
     else if (s == 256)
-      e = 0x30u | (uint32_t)l;
+      e = 0x3000u | ((uint32_t)l << 8) | (uint32_t)l;
     else if (s - 257 < 29)
-      e = ((uint32_t)LEN_BASE[s - 257] << 16) | ((uint32_t)LEN_EXTRA[s - 257] << 8) | 0x20u | (uint32_t)l;
+      e = ((uint32_t)LEN_BASE[s - 257] << 16) | 0x2000u | ((uint32_t)l << 8) | (uint32_t)(l + LEN_EXTRA[s - 257]);
     else
-      e = 0x20u | (uint32_t)l; /* 286, 287: codes without a meaning (base 0) */
+      e = 0x2000u | ((uint32_t)l << 8) | (uint32_t)l; /* 286, 287: codes without a meaning (base 0) */
     for (uint32_t i = r; i < (1u << WIDE_BITS); i += 1u << l) h->wide[i] = e;
   }
 }
 
-/* ... and of a distance code: [3:0] code length, [11:8] extra bits, [31:16] distance base (0: codes 30, 31) */
+/* ... and of a distance code: [7:0] bits to consume in all, [11:8] code length, [31:16] distance base (0: codes 30, 31) */
 static void huff_widen_dist(huff_t *h) {
   uint16_t next[MAXBITS + 1];
   uint32_t code = 0;
@@ -178,7 +180,7 @@ static void huff_widen_dist(huff_t *h) {
     if (l > WIDE_BITS) continue;
     uint32_t r = 0;
     for (int i = 0; i < l; ++i) r |= ((c >> i) & 1u) << (l - 1 - i);
-    const uint32_t e = s < 30 ? ((uint32_t)DIST_BASE[s] << 16) | ((uint32_t)DIST_EXTRA[s] << 8) | (uint32_t)l : (uint32_t)l;
+    const uint32_t e = s < 30 ? ((uint32_t)DIST_BASE[s] << 16) | ((uint32_t)l << 8) | (uint32_t)(l + DIST_EXTRA[s]) : ((uint32_t)l << 8) | (uint32_t)l;
     for (uint32_t i = r; i < (1u << WIDE_BITS); i += 1u << l) h->wide[i] = e;
   }
 }
@@ -353,8 +355,12 @@ static int coded_block(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_
   return bits_pos(b) > (uint64_t)b->n * 8u ? PI_ERR_INPUT : PI_OK;
 }
 
-/* The same for the real decoder: the wide table (huff_widen), up to three literals per refill, matches copied in
- * 16-byte pieces (it wants 280 symbols of room in front of every step: PI_ERR_SPACE earlier than strictly needed). */
+/* The same for the real decoder.  gzip -1 turns FASTQ into SHORT MATCHES (bases and binned qualities: five bytes per
+ * match on average, hardly a literal), so what bounds the loop is the chain look-up -> shift -> look-up of a match's
+ * two codes: the wide tables hold the bits to consume in ONE field that the shift uses as it is, the extra bits are
+ * cut out of a copy of the bit buffer beside the chain, one refill serves a whole match (56 bits >= 15 + 5 + 15 + 13),
+ * and a match of up to 16 symbols is two unconditional 16-byte copies.  (It wants 280 symbols of room in front of
+ * every step: PI_ERR_SPACE earlier than strictly needed.) */
 static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_t *out, size_t cap, size_t *o) {
   size_t at = *o;
   const uint32_t *lt = lit->wide, *dt = dist->wide;
@@ -383,8 +389,12 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
     }                                            \
   } while (0)
 #define PI_SYNC() (b->pos = pos, b->buf = buf, b->cnt = cnt)
+/* consume the entry's bits; `saved_` keeps the buffer for the extra bits */
+#define PI_TAKE(e_) (saved = buf, buf >>= ((e_) & 63u), cnt -= (int)((e_) & 63u))
+/* the extra bits of the entry just taken: the low (total) bits of the saved buffer above the code */
+#define PI_EXTRA(e_) ((uint32_t)((saved & ((1ull << ((e_) & 63u)) - 1ull)) >> (((e_) >> 8) & 15u)))
   for (;;) {
-    if (at + 280 > cap) {  /* four literals + the longest match + the overshoot of its last piece */
+    if (at + 280 > cap) {  /* two literals + the longest match + the overshoot of its last piece */
       rc = PI_ERR_SPACE;
       break;
     }
@@ -393,34 +403,30 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
       rc = PI_ERR_INPUT;
       break;
     }
+    uint64_t saved;
     uint32_t e = lt[buf & mask];
-    /* up to four literals from one refill (4 x 11 bits of >= 56) */
-    if ((e & 0x30u) == 0x10u) {
-      buf >>= (e & 15u);
-      cnt -= (int)(e & 15u);
+    if ((e & 0x3000u) == 0x1000u) {  /* literals: up to four from one refill (4 x 11 bits of >= 56) */
+      PI_TAKE(e);
       out[at++] = (uint16_t)(e >> 16);
       e = lt[buf & mask];
-      if ((e & 0x30u) == 0x10u) {
-        buf >>= (e & 15u);
-        cnt -= (int)(e & 15u);
+      if ((e & 0x3000u) == 0x1000u) {
+        PI_TAKE(e);
         out[at++] = (uint16_t)(e >> 16);
         e = lt[buf & mask];
-        if ((e & 0x30u) == 0x10u) {
-          buf >>= (e & 15u);
-          cnt -= (int)(e & 15u);
+        if ((e & 0x3000u) == 0x1000u) {
+          PI_TAKE(e);
           out[at++] = (uint16_t)(e >> 16);
           e = lt[buf & mask];
-          if ((e & 0x30u) == 0x10u) {
-            buf >>= (e & 15u);
-            cnt -= (int)(e & 15u);
+          if ((e & 0x3000u) == 0x1000u) {
+            PI_TAKE(e);
             out[at++] = (uint16_t)(e >> 16);
             continue;
           }
         }
       }
+      /* not a literal; the look-up is still good behind a refill (that only adds bits on top) */
+      PI_REFILL();
     }
-    /* not a literal; the look-up is still good behind a refill (that only adds bits on top) */
-    PI_REFILL();
     int length;
     if (e == 0) { /* a code longer than WIDE_BITS (or none): the canonical walk */
       PI_SYNC();
@@ -445,29 +451,21 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
       buf >>= LEN_EXTRA[sym];
       cnt -= LEN_EXTRA[sym];
     } else {
-      if ((e & 0x30u) == 0x30u) { /* end of block */
-        buf >>= (e & 15u);
-        cnt -= (int)(e & 15u);
-        break;
-      }
-      const uint32_t cl = e & 15u, xb = (e >> 8) & 15u; /* code and extra bits in one step */
-      length = (int)(e >> 16) + (int)((buf >> cl) & ((1u << xb) - 1u));
-      buf >>= cl + xb;
-      cnt -= (int)(cl + xb);
+      PI_TAKE(e);
+      if ((e & 0x3000u) == 0x3000u) break; /* end of block */
+      length = (int)(e >> 16) + (int)PI_EXTRA(e);
       if ((e >> 16) == 0) { /* symbols 286 / 287 */
         rc = PI_ERR_DATA;
         break;
       }
     }
-    /* >= 56 - 16 - 5 = 35 bits left: 15 + 13 for the distance */
+    /* >= 56 - 15 - 5 = 36 bits left: 15 + 13 for the distance */
     int d;
     {
       const uint32_t de = dt[buf & mask];
-      if (de & 15u) {
-        const uint32_t cl = de & 15u, xb = (de >> 8) & 15u;
-        d = (int)(de >> 16) + (int)((buf >> cl) & ((1u << xb) - 1u));
-        buf >>= cl + xb;
-        cnt -= (int)(cl + xb);
+      if (de) {
+        PI_TAKE(de);
+        d = (int)(de >> 16) + (int)PI_EXTRA(de);
         if ((de >> 16) == 0) { /* codes 30 / 31 */
           rc = PI_ERR_DATA;
           break;
@@ -488,9 +486,11 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
     uint16_t *dst = out + at;
     if ((size_t)d <= at) {
       const uint16_t *src = dst - d;
-      if (d >= 8) {
+      if (d >= 8) {  /* pieces of eight symbols, one behind the other: a piece may read what the one before wrote */
         memcpy(dst, src, 16);
-        for (int j = 8; j < length; j += 8) memcpy(dst + j, src + j, 16);
+        memcpy(dst + 8, src + 8, 16);
+        if (length > 16)
+          for (int j = 16; j < length; j += 8) memcpy(dst + j, src + j, 16);
       } else {
         for (int j = 0; j < length; ++j) dst[j] = src[j];
       }
@@ -506,6 +506,8 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
   PI_SYNC();
 #undef PI_REFILL
 #undef PI_SYNC
+#undef PI_TAKE
+#undef PI_EXTRA
   *o = at;
   if (rc != PI_OK) return rc;
   return bits_pos(b) > (uint64_t)b->n * 8u ? PI_ERR_INPUT : PI_OK;
