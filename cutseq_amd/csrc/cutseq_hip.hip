@@ -747,13 +747,19 @@ int cs_plan_set_demux_ops(cs_plan *plan, int mate, int op_index, const cs_op *op
         for (int j = 0; j < d.op.m; ++j) d.op.seq[j] = (uint8_t)csdev::base_code(d.op.seq[j]);
       dl.ops.push_back(d);
     }
-    dl.depth = std::min((int)op.m + (int)op.k, 9);
-    std::vector<size_t> block(dl.depth + 2, 0);
-    size_t pw = 1;
-    for (int l = 0; l <= dl.depth; ++l, pw *= 5) block[l + 1] = block[l] + pw;
-    dl.first.assign(block[dl.depth + 1], 0u);
-    if (!demux_walk_all(digits, (int)op.m, (int)op.k, dl, block))
-      return fail(CS_ERR_ARG, "demux: candidate lists exceed the table format");
+    // nine bases deep where the lists fit the table format (16 M entries); many long barcodes with many errors: one
+    // base less at a time (shorter prefixes, fewer and longer lists -- the device tries a few more barcodes per read)
+    bool fits = false;
+    for (int depth = std::min((int)op.m + (int)op.k, 9); depth >= 1 && !fits; --depth) {
+      dl.depth = depth;
+      dl.pool.clear();
+      std::vector<size_t> block(depth + 2, 0);
+      size_t pw = 1;
+      for (int l = 0; l <= depth; ++l, pw *= 5) block[l + 1] = block[l] + pw;
+      dl.first.assign(block[depth + 1], 0u);
+      fits = demux_walk_all(digits, (int)op.m, (int)op.k, dl, block);
+    }
+    if (!fits) return fail(CS_ERR_ARG, "demux: candidate lists exceed the table format");
     plan->demux_long[mate - 1][op_index] = std::move(dl);
   } catch (const std::bad_alloc &) {
     return fail(CS_ERR_NOMEM, "out of memory");

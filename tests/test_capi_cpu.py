@@ -132,6 +132,17 @@ def test_long_barcodes_take_their_own_ops_not_a_table(lib):
     assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 255) == 0, lib.cs_last_error()
     assert time.perf_counter() - t0 < 30.0
     lib.cs_plan_destroy(h)
+    # a 255-plex of 20-mers with four errors: the lists of nine-base prefixes exceed the table format, the library
+    # settles for shorter prefixes instead of refusing the plan
+    codes = sorted({"".join(rng.choice("ACGT") for _ in range(20)) for _ in range(300)})[:255]
+    st.demux_barcodes = codes
+    tp = planmod.compile_paired(BarcodeConfig(scheme.replace("ACGTACGTACGT", codes[0])), st)
+    assert (tp.demux.m, tp.demux.k) == (20, 4)
+    rc, h = _create(lib, tp)
+    assert rc == 0
+    ops = planmod.pack_ops(tp.demux.barcode_ops(), limit=255)
+    assert lib.cs_plan_set_demux_ops(h, 1, index, C.cast(ops, C.c_void_p), 255) == 0, lib.cs_last_error()
+    lib.cs_plan_destroy(h)
     # limits and placement
     st.demux_barcodes = ["A" * 21 + "C", "C" * 21 + "A"]  # m + k = 22 + 4
     with pytest.raises(ValueError):
