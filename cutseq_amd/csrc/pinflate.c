@@ -88,7 +88,10 @@ typedef struct {
    * its base and extra-bit count) and end of block apart.  [7:0] bits to consume in all, code + extra bits (0: a code
    * longer than WIDE_BITS or none) -- the decoder shifts by the entry itself, the dependent chain from one look-up to
    * the next is mask, load, shift --, [11:8] code length (where the extra bits start), [13:12] 1 literal / 2 length /
-   * 3 end of block, [31:16] literal or length base (0: invalid). */
+   * 3 end of block, [31:16] literal or length base (0: invalid).
+   * Kind 0 with a non-zero entry is a WHOLE MATCH (huff_combine): a length code without extra bits (lengths 3..10)
+   * and the distance code behind it both fit the index -- [5:0] bits to consume in all (both codes and the
+   * distance's extra bits), [11:8] distance extra bits, [16:14] length - 3, [31:17] distance base. */
   uint32_t wide[1 << WIDE_BITS];
 } huff_t;
 
@@ -183,6 +186,25 @@ static void huff_widen_dist(huff_t *h) {
     for (int i = 0; i < l; ++i) r |= ((c >> i) & 1u) << (l - 1 - i);
     const uint32_t e = s < 30 ? ((uint32_t)DIST_BASE[s] << 16) | ((uint32_t)l << 8) | (uint32_t)(l + DIST_EXTRA[s]) : ((uint32_t)l << 8) | (uint32_t)l;
     for (uint32_t i = r; i < (1u << WIDE_BITS); i += 1u << l) h->wide[i] = e;
+  }
+}
+
+/* gzip -1 turns FASTQ into short matches, and a match is two codes: look-up, shift, look-up, shift.  Where a length
+ * code without extra bits and the distance code behind it fit the index together, the literal / length table gets
+ * an entry for the whole match (see huff_t): one look-up and one shift per match on the decoder's dependent chain. */
+static void huff_combine(huff_t *lit, const huff_t *dist) {
+  for (uint32_t i = 0; i < (1u << WIDE_BITS); ++i) {
+    const uint32_t e = lit->wide[i];
+    if ((e & 0x3000u) != 0x2000u) continue;          /* not a length */
+    const uint32_t l = (e >> 8) & 15u;
+    if ((e & 0xffu) != l || (e >> 16) < 3 || (e >> 16) > 10) continue; /* extra bits (or no meaning) */
+    const uint32_t rem = WIDE_BITS - l;
+    if (rem == 0) continue;
+    const uint32_t de = dist->wide[(i >> l) & ((1u << rem) - 1u)];
+    const uint32_t dl = (de >> 8) & 15u;
+    if (de == 0 || dl > rem || (de >> 16) == 0) continue; /* the distance code is longer than what the index shows */
+    const uint32_t xb = (de & 0xffu) - dl, total = l + (de & 0xffu);
+    lit->wide[i] = total | (xb << 8) | (((e >> 16) - 3u) << 14) | ((de >> 16) << 17);
   }
 }
 
@@ -284,6 +306,7 @@ static void fixed_codes(void) {
   for (s = 0; s < 30; ++s) len[s] = 5;
   huff_build(&d, len, 30);
   huff_widen_dist(&d);
+  huff_combine(&l, &d);
   if (!g_fixed_ready) {
     g_fixed_lit = l;
     g_fixed_dist = d;
@@ -360,7 +383,7 @@ static int coded_block(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_
  * match on average, hardly a literal), so what bounds the loop is the chain look-up -> shift -> look-up of a match's
  * two codes: the wide tables hold the bits to consume in ONE field that the shift uses as it is, the extra bits are
  * cut out of a copy of the bit buffer beside the chain, one refill serves a whole match (56 bits >= 15 + 5 + 15 + 13),
- * and a match of up to 16 symbols is two unconditional 16-byte copies.  (It wants 280 symbols of room in front of
+ * and a match of up to 16 symbols is two unconditional 16-byte copies.  (It wants 320 symbols of room in front of
  * every step: PI_ERR_SPACE earlier than strictly needed.) */
 static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_t *out, size_t cap, size_t *o) {
   size_t at = *o;
@@ -395,7 +418,7 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
 /* the extra bits of the entry just taken: the low (total) bits of the saved buffer above the code */
 #define PI_EXTRA(e_) ((uint32_t)((saved & ((1ull << ((e_) & 63u)) - 1ull)) >> (((e_) >> 8) & 15u)))
   for (;;) {
-    if (at + 280 > cap) {  /* two literals + the longest match + the overshoot of its last piece */
+    if (at + 320 > cap) {  /* four literals + the longest match + the overshoot of its last piece, or two short matches */
       rc = PI_ERR_SPACE;
       break;
     }
@@ -406,6 +429,32 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
     }
     uint64_t saved;
     uint32_t e = lt[buf & mask];
+    if ((e & 0x3000u) == 0 && e != 0) {  /* a whole match in one entry (huff_combine) */
+    whole_match:
+      /* TWO of them from one refill (2 x 24 bits of >= 56): the refill -- count, position, load, shift, or -- is a
+       * dependent chain of its own, twice as long as look-up -> shift -> look-up */
+      for (int twice = 0;; ++twice) {
+        PI_TAKE(e);
+        const int length = 3 + (int)((e >> 14) & 7u);
+        const uint32_t tot = e & 63u, xb = (e >> 8) & 15u;
+        const int d = (int)(e >> 17) + (int)((uint32_t)((saved & ((1ull << tot) - 1ull)) >> (tot - xb)));
+        uint16_t *dst = out + at;
+        if ((size_t)d <= at && d >= 8) {
+          memcpy(dst, dst - d, 16);
+          memcpy(dst + 8, dst - d + 8, 4);  /* (lengths up to 10) */
+        } else {
+          for (int j = 0; j < length; ++j) {
+            const int64_t from = (int64_t)at + j - d;
+            dst[j] = from < 0 ? (uint16_t)(0x8000u | (uint32_t)(WINDOW + from)) : out[from];
+          }
+        }
+        at += (size_t)length;
+        if (twice || cnt < 24) break;
+        e = lt[buf & mask];
+        if (!((e & 0x3000u) == 0 && e != 0)) break;  /* (looked up again behind the refill) */
+      }
+      continue;
+    }
     if ((e & 0x3000u) == 0x1000u) {  /* literals: up to four from one refill (4 x 11 bits of >= 56) */
       PI_TAKE(e);
       out[at++] = (uint16_t)(e >> 16);
@@ -427,6 +476,7 @@ static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, ui
       }
       /* not a literal; the look-up is still good behind a refill (that only adds bits on top) */
       PI_REFILL();
+      if ((e & 0x3000u) == 0 && e != 0) goto whole_match;
     }
     int length;
     if (e == 0) { /* a code longer than WIDE_BITS (or none): the canonical walk */
@@ -616,6 +666,7 @@ int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int
       if (rc) break;
       huff_widen(lit);
       huff_widen_dist(dist);
+      huff_combine(lit, dist);
       rc = coded_block_fast(&b, lit, dist, out, (size_t)cap, &o);
       if (rc) break;
     } else {
