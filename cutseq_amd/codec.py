@@ -223,6 +223,11 @@ class GzipSource:
         self.size = self.fh.seek(0, 2)
         self.fh.seek(0)
         self.map = mmap.mmap(self.fh.fileno(), 0, access=mmap.ACCESS_READ) if self.size else None
+        self._open = True
+        with _lib_lock:
+            GzipSource._active += 1
+
+    _active = 0  # sources open right now: they share the pool (how far each one speculates ahead)
 
     def _posted(self, out, produced):
         if self.post is not None and out is not None:
@@ -232,6 +237,10 @@ class GzipSource:
         return self._side.pop(arr.ctypes.data, None)
 
     def close(self):
+        if self._open:
+            self._open = False
+            with _lib_lock:
+                GzipSource._active -= 1
         if self.map is not None:
             try:
                 self.map.close()
@@ -336,7 +345,9 @@ class GzipSource:
         buf, n = self.map, self.size
         # candidates in flight beyond the current member: enough to keep the whole pool busy from ONE file (single-end
         # runs; eight left half of a 16-thread pool idle: 3.0 GB/s of text from one file against 6.8 from two)
-        window = max(8, getattr(self.pool, "_max_workers", 8))
+        # (two files of a paired run share the pool: half each -- more only queues speculation in front of the members the
+        # other file is waiting for)
+        window = max(8, getattr(self.pool, "_max_workers", 8) // max(1, GzipSource._active))
         tasks = {}  # member start -> future of _inflate_member_at
         cands = []  # ascending candidate starts behind the current member
         scan_from = start + 1
@@ -359,7 +370,6 @@ class GzipSource:
             while head < n:
                 if buf[head] == 0 and not any(buf[head:min(n, head + (1 << 20))]):
                     return  # zero padding after the last member (tar-style): done
-                submit(head)
                 # (member starts are looked for in the next 64 MB of compressed bytes only: mmap.find holds the GIL, and on
                 # one huge member -- no magic anywhere -- it would walk the whole file while every other thread waits)
                 ahead = min(n, head + _MEMBER_CAP // 4 + 2)
@@ -371,6 +381,17 @@ class GzipSource:
                     scan_from = p + 1
                     if p + 18 <= n and (buf[p + 3] & 0xE0) == 0:
                         cands.append(p)
+                if not cands and head not in tasks:
+                    # No member starts anywhere near: one huge member, the usual sequencer output.  Inflating its first
+                    # 32 MB only to learn that it does not fit costs the run 30 ms with every other thread idle; it
+                    # cannot fit when its compressed bytes alone exceed the buffer (deflate never expands by more than
+                    # a few bytes per block), or when it is the file's last member and the trailer says so.
+                    span = ahead - head
+                    isize = struct.unpack_from("<I", buf, n - 4)[0] if ahead == n and n - head >= 18 else 0
+                    if span > cap[0] or isize > cap[0]:
+                        yield from self._big_member(head)
+                        return
+                submit(head)
                 for p in cands:
                     submit(p)
                 rc, used, out, produced = tasks.pop(head).result()
@@ -484,25 +505,41 @@ class GzipSource:
                     return rc, 0, 0, None, 0
                 return 0, eb.value, fin.value, raw, no.value
 
+        import time
+        T = self.stats  # (diagnostics: seconds per phase, summed over the threads)
+
+        def tick(key, t0):
+            t1 = time.perf_counter()
+            T[key] = T.get(key, 0.0) + (t1 - t0)
+            return t1
+
         def speculate(i):
+            t0 = time.perf_counter()
             lo = i * S * 8
             start = 0 if i == 0 else H.csh_deflate_find_block(base, n, lo, min(n * 8, lo + 2 * S * 8))
+            t0 = tick("find_s", t0)
             if start < 0:
                 return start, (-1, 0, 0, None, 0)
-            return start, decode(start, (i + 1) * S * 8)
+            got = decode(start, (i + 1) * S * 8)
+            tick("decode_s", t0)
+            return start, got
 
         def resolve(raw, n_sym, window):
+            t0 = time.perf_counter()
             sym = raw[: 2 * n_sym].view(np.uint16)
             out = self.take(max(n_sym, 1))
             markers = H.csh_resolve_markers(sym.ctypes.data, n_sym, window.ctypes.data if window is not None else None, out.ctypes.data)
             self.give(raw)
+            t0 = tick("resolve_s", t0)
             if markers < 0:
                 self.give(out)
                 raise OSError(f"{self.path}: corrupt gzip data (a back-reference in front of the stream's start)")
             # (carry-less multiply: 8 GB/s; the zlib 1.2.11 Python links does 1 GB/s -- as long as the resolve pass itself)
             L = libdeflate()
             crc = L.libdeflate_crc32(0, out.ctypes.data, n_sym) if L is not None else zlib.crc32(memoryview(out)[:n_sym])
+            t0 = tick("crc_s", t0)
             self._posted(out, n_sym)
+            tick("post_s", t0)
             return out, n_sym, crc
 
         ahead = 2 * workers
@@ -517,7 +554,9 @@ class GzipSource:
                     spec[next_submit] = self.pool.submit(speculate, next_submit)
                     next_submit += 1
                 if i < n_chunks:
+                    t0 = time.perf_counter()
                     start, (rc, end_bit, fin, raw, n_sym) = spec.pop(i).result()
+                    tick("main_wait_s", t0)
                 else:
                     start, rc, raw = -1, -1, None
                 self.stats["chunks"] = self.stats.get("chunks", 0) + 1

@@ -50,6 +50,6 @@ for kind in ("syn", "single"):
                 t.join()
             dt = time.perf_counter() - t0
             tot = sum(b[0] for b in box)
-            print(f"{kind:6s} {len(use)} file(s): {tot / dt / 1e9:6.2f} GB/s of text ({dt:.3f} s) {box[0][1]}", flush=True)
+            print(f"{kind:6s} {len(use)} file(s): {tot / dt / 1e9:6.2f} GB/s of text ({dt:.3f} s) { {k: (round(v, 3) if isinstance(v, float) else v) for k, v in box[0][1].items()} }", flush=True)
 import shutil
 shutil.rmtree(work, ignore_errors=True)
