@@ -1,4 +1,5 @@
-"""Host-side record logic: header rewriting, pair routing and FASTQ formatting.
+"""Record logic as a SPECIFICATION (test infrastructure, not on the product path: the product formats on the device,
+text_kernels.hip.inc, or through csh_format_chunk): header rewriting, pair routing and FASTQ formatting.
 
 This is the string work the reference leaves to cutadapt's ``SuffixRemover``,
 ``Renamer`` / ``PairedEndRenamer`` (cutseq/run.py:330, 377-380, 537-542, 642-645), the
@@ -9,7 +10,7 @@ from __future__ import annotations
 
 from typing import Sequence, Tuple
 
-from . import abi
+from cutseq_amd import abi
 
 ROUTE_TRIMMED, ROUTE_SHORT, ROUTE_UNTRIMMED = 0, 1, 2
 ROUTE_NAMES = ("trimmed", "short", "untrimmed")

@@ -27,7 +27,8 @@ from test_oracle import CHAIN_CASES  # noqa: E402
 def bins_case(seed: int) -> None:
     """One demultiplexing batch through the text path (one route per barcode), expected from the array API's results and
     barcode indices (held to the oracle by tests/test_gpu_demux.py) formatted by the record logic."""
-    from cutseq_amd import abi, hostfmt
+    from cutseq_amd import abi
+    import hostfmt
     from cutseq_amd.common import BarcodeConfig
     from test_gpu_demux import barcode_set, plant_barcodes, scheme_with
     rng = random.Random(seed)

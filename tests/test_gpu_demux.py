@@ -207,7 +207,8 @@ def test_demux_on_the_3prime_barcode_of_single_end_reads(length, count, text):
         want1["flags"] |= np.where(amb, abi.CS_F_AMBIGUOUS, 0).astype(np.uint8)
         assert np.array_equal(g1, want1)
         return
-    from cutseq_amd import hostfmt, textpath
+    from cutseq_amd import textpath
+    import hostfmt
     names = [f"SE:{i} 1:N:0:X".encode() for i in range(n)]
     text1 = b"".join(b"@" + names[i] + b"\n" + batch.seq1[i, :batch.len1[i]].tobytes() + b"\n+\n" +
                      batch.qual1[i, :batch.len1[i]].tobytes() + b"\n" for i in range(n))
@@ -262,7 +263,8 @@ def test_cli_demultiplexes_like_independent_runs(tmp_path, monkeypatch):
     import json
     import zlib
 
-    from cutseq_amd import hostfmt, run as cli
+    from cutseq_amd import run as cli
+    import hostfmt
 
     rng = random.Random(11)
     length, count, n = 8, 16, 40_000

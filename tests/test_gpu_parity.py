@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle
-from cutseq_amd import abi, hostfmt, plan as planmod, synth
+from cutseq_amd import abi, plan as planmod, synth
+import hostfmt
 from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
 from cutseq_amd.engine import TrimEngine
 from cutseq_amd.synth import SynthBatch

@@ -220,7 +220,7 @@ def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired, le
     of 64 bases for 150-base reads, so every read takes the long-read kernel, which knows both forms too."""
     import gzip
     import random
-    from cutseq_amd import hostfmt
+    import hostfmt
     from test_gpu_demux import barcode_set, plant_barcodes, scheme_with
     rng = random.Random(77)
     codes = barcode_set(rng, 24, length, 4)

@@ -9,7 +9,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from cutseq_amd import abi, fastq, hostfmt, plan as planmod, run as cli
+from cutseq_amd import abi, fastq, plan as planmod, run as cli
+import hostfmt
 from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
 
 import util

@@ -16,7 +16,8 @@ import pytest
 
 import oracle
 from oracle import pyref
-from cutseq_amd import abi, hostfmt, plan as planmod, synth
+from cutseq_amd import abi, plan as planmod, synth
+import hostfmt
 from cutseq_amd.common import BUILDIN_ADAPTERS, BarcodeConfig
 
 import util

@@ -10,7 +10,8 @@ import numpy as np
 
 import oracle
 from oracle import pyref
-from cutseq_amd import abi, hostfmt, plan as planmod
+from cutseq_amd import abi, plan as planmod
+import hostfmt
 from cutseq_amd.common import BarcodeConfig
 from cutseq_amd.synth import SynthBatch
 
