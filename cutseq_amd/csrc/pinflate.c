@@ -750,3 +750,15 @@ int64_t csh_next_window(const uint16_t *sym, int64_t n, const uint8_t *window, u
    * copied, `window` itself is untouched) */
   return csh_resolve_markers(sym, n, window, next + keep);
 }
+
+/* First position p in [from, to) with buf[p .. p+2] == 1f 8b 08 (a gzip member header with the deflate method), -1 if
+ * none; `to` may be at most n - 2.  (mmap.find holds the interpreter lock and walks 1 GB/s; this is memchr.) */
+int64_t csh_find_gzip_magic(const uint8_t *buf, int64_t from, int64_t to) {
+  while (from < to) {
+    const uint8_t *hit = (const uint8_t *)memchr(buf + from, 0x1f, (size_t)(to - from));
+    if (!hit) return -1;
+    if (hit[1] == 0x8b && hit[2] == 0x08) return (int64_t)(hit - buf);
+    from = (int64_t)(hit - buf) + 1;
+  }
+  return -1;
+}
