@@ -48,12 +48,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 HOST_SRC = HERE / "csrc" / "cutseq_host.c"
 HOST_SRCS = (HOST_SRC, HERE / "csrc" / "pinflate.c")
+HOST_DEPS = HOST_SRCS + (HERE / "csrc" / "pinflate_loop.h",)
 HOST_OUT = HERE / "libcutseq_host.so"
 
 
 def build_host(force: bool = False) -> Path:
     """Host-only helpers (synthetic generator): plain gcc, no GPU toolchain involved."""
-    if not force and HOST_OUT.exists() and HOST_OUT.stat().st_mtime >= max(p.stat().st_mtime for p in HOST_SRCS):
+    if not force and HOST_OUT.exists() and HOST_OUT.stat().st_mtime >= max(p.stat().st_mtime for p in HOST_DEPS):
         return HOST_OUT
     cmd = ["gcc", "-O3", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-o", str(HOST_OUT)] + [str(p) for p in HOST_SRCS] + ["-lpthread"]
     subprocess.run(cmd, check=True)

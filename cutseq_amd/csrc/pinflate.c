@@ -18,6 +18,7 @@
  *   csh_inflate_chunk        decode from a block boundary up to the first block boundary at or behind `stop_bit`
  *                            (or the end of the final block) into 16-bit symbols
  *   csh_resolve_markers      symbols + the 32 KB window in front of the chunk -> bytes
+ *   csh_inflate_stream       a whole stream from its start (a gzip member), straight into bytes
  *
  * RFC 1951 throughout; the Huffman construction follows its section 3.2.2, the slow decoding loop is the canonical
  * count / first-code walk. */
@@ -385,184 +386,20 @@ static int coded_block(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_
  * cut out of a copy of the bit buffer beside the chain, one refill serves a whole match (56 bits >= 15 + 5 + 15 + 13),
  * and a match of up to 16 symbols is two unconditional 16-byte copies.  (It wants 320 symbols of room in front of
  * every step: PI_ERR_SPACE earlier than strictly needed.) */
-static int coded_block_fast(bits_t *b, const huff_t *lit, const huff_t *dist, uint16_t *out, size_t cap, size_t *o) {
-  size_t at = *o;
-  const uint32_t *lt = lit->wide, *dt = dist->wide;
-  const uint32_t mask = (1u << WIDE_BITS) - 1u;
-  /* the bit reader's state in locals for the length of the block */
-  const uint8_t *in = b->in;
-  const size_t n = b->n;
-  size_t pos = b->pos;
-  uint64_t buf = b->buf;
-  int cnt = b->cnt;
-  int rc = PI_OK;
-#define PI_REFILL()                              \
-  do {                                           \
-    if (pos + 8 <= n) {                          \
-      uint64_t w_;                               \
-      memcpy(&w_, in + pos, 8);                  \
-      buf |= w_ << cnt;                          \
-      pos += (size_t)((63 - cnt) >> 3);          \
-      cnt |= 56;                                 \
-    } else {                                     \
-      while (cnt <= 56) {                        \
-        buf |= (uint64_t)(pos < n ? in[pos] : 0) << cnt; \
-        pos++;                                   \
-        cnt += 8;                                \
-      }                                          \
-    }                                            \
-  } while (0)
-#define PI_SYNC() (b->pos = pos, b->buf = buf, b->cnt = cnt)
-/* consume the entry's bits; `saved_` keeps the buffer for the extra bits */
-#define PI_TAKE(e_) (saved = buf, buf >>= ((e_) & 63u), cnt -= (int)((e_) & 63u))
-/* the extra bits of the entry just taken: the low (total) bits of the saved buffer above the code */
-#define PI_EXTRA(e_) ((uint32_t)((saved & ((1ull << ((e_) & 63u)) - 1ull)) >> (((e_) >> 8) & 15u)))
-  for (;;) {
-    if (at + 320 > cap) {  /* four literals + the longest match + the overshoot of its last piece, or two short matches */
-      rc = PI_ERR_SPACE;
-      break;
-    }
-    PI_REFILL();
-    if (pos > n + 16) {
-      rc = PI_ERR_INPUT;
-      break;
-    }
-    uint64_t saved;
-    uint32_t e = lt[buf & mask];
-    if ((e & 0x3000u) == 0 && e != 0) {  /* a whole match in one entry (huff_combine) */
-    whole_match:
-      /* TWO of them from one refill (2 x 24 bits of >= 56): the refill -- count, position, load, shift, or -- is a
-       * dependent chain of its own, twice as long as look-up -> shift -> look-up */
-      for (int twice = 0;; ++twice) {
-        PI_TAKE(e);
-        const int length = 3 + (int)((e >> 14) & 7u);
-        const uint32_t tot = e & 63u, xb = (e >> 8) & 15u;
-        const int d = (int)(e >> 17) + (int)((uint32_t)((saved & ((1ull << tot) - 1ull)) >> (tot - xb)));
-        uint16_t *dst = out + at;
-        if ((size_t)d <= at && d >= 8) {
-          memcpy(dst, dst - d, 16);
-          memcpy(dst + 8, dst - d + 8, 4);  /* (lengths up to 10) */
-        } else {
-          for (int j = 0; j < length; ++j) {
-            const int64_t from = (int64_t)at + j - d;
-            dst[j] = from < 0 ? (uint16_t)(0x8000u | (uint32_t)(WINDOW + from)) : out[from];
-          }
-        }
-        at += (size_t)length;
-        if (twice || cnt < 24) break;
-        e = lt[buf & mask];
-        if (!((e & 0x3000u) == 0 && e != 0)) break;  /* (looked up again behind the refill) */
-      }
-      continue;
-    }
-    if ((e & 0x3000u) == 0x1000u) {  /* literals: up to four from one refill (4 x 11 bits of >= 56) */
-      PI_TAKE(e);
-      out[at++] = (uint16_t)(e >> 16);
-      e = lt[buf & mask];
-      if ((e & 0x3000u) == 0x1000u) {
-        PI_TAKE(e);
-        out[at++] = (uint16_t)(e >> 16);
-        e = lt[buf & mask];
-        if ((e & 0x3000u) == 0x1000u) {
-          PI_TAKE(e);
-          out[at++] = (uint16_t)(e >> 16);
-          e = lt[buf & mask];
-          if ((e & 0x3000u) == 0x1000u) {
-            PI_TAKE(e);
-            out[at++] = (uint16_t)(e >> 16);
-            continue;
-          }
-        }
-      }
-      /* not a literal; the look-up is still good behind a refill (that only adds bits on top) */
-      PI_REFILL();
-      if ((e & 0x3000u) == 0 && e != 0) goto whole_match;
-    }
-    int length;
-    if (e == 0) { /* a code longer than WIDE_BITS (or none): the canonical walk */
-      PI_SYNC();
-      int sym = huff_decode(b, lit);
-      pos = b->pos, buf = b->buf, cnt = b->cnt;
-      if (sym < 0) {
-        rc = PI_ERR_DATA;
-        break;
-      }
-      if (sym < 256) {
-        out[at++] = (uint16_t)sym;
-        continue;
-      }
-      if (sym == 256) break;
-      sym -= 257;
-      if (sym >= 29) {
-        rc = PI_ERR_DATA;
-        break;
-      }
-      PI_REFILL();
-      length = LEN_BASE[sym] + (int)(buf & ((1u << LEN_EXTRA[sym]) - 1u));
-      buf >>= LEN_EXTRA[sym];
-      cnt -= LEN_EXTRA[sym];
-    } else {
-      PI_TAKE(e);
-      if ((e & 0x3000u) == 0x3000u) break; /* end of block */
-      length = (int)(e >> 16) + (int)PI_EXTRA(e);
-      if ((e >> 16) == 0) { /* symbols 286 / 287 */
-        rc = PI_ERR_DATA;
-        break;
-      }
-    }
-    /* >= 56 - 15 - 5 = 36 bits left: 15 + 13 for the distance */
-    int d;
-    {
-      const uint32_t de = dt[buf & mask];
-      if (de) {
-        PI_TAKE(de);
-        d = (int)(de >> 16) + (int)PI_EXTRA(de);
-        if ((de >> 16) == 0) { /* codes 30 / 31 */
-          rc = PI_ERR_DATA;
-          break;
-        }
-      } else {
-        PI_SYNC();
-        const int ds = huff_decode(b, dist);
-        pos = b->pos, buf = b->buf, cnt = b->cnt;
-        if (ds < 0 || ds >= 30) {
-          rc = PI_ERR_DATA;
-          break;
-        }
-        d = DIST_BASE[ds] + (int)(buf & ((1u << DIST_EXTRA[ds]) - 1u));
-        buf >>= DIST_EXTRA[ds];
-        cnt -= DIST_EXTRA[ds];
-      }
-    }
-    uint16_t *dst = out + at;
-    if ((size_t)d <= at) {
-      const uint16_t *src = dst - d;
-      if (d >= 8) {  /* pieces of eight symbols, one behind the other: a piece may read what the one before wrote */
-        memcpy(dst, src, 16);
-        memcpy(dst + 8, src + 8, 16);
-        if (length > 16)
-          for (int j = 16; j < length; j += 8) memcpy(dst + j, src + j, 16);
-      } else {
-        for (int j = 0; j < length; ++j) dst[j] = src[j];
-      }
-    } else {
-      /* reaches in front of the chunk: markers for that part, then the chunk's own symbols */
-      for (int j = 0; j < length; ++j) {
-        const int64_t from = (int64_t)at + j - d;
-        dst[j] = from < 0 ? (uint16_t)(0x8000u | (uint32_t)(WINDOW + from)) : out[from];
-      }
-    }
-    at += (size_t)length;
-  }
-  PI_SYNC();
-#undef PI_REFILL
-#undef PI_SYNC
-#undef PI_TAKE
-#undef PI_EXTRA
-  *o = at;
-  if (rc != PI_OK) return rc;
-  return bits_pos(b) > (uint64_t)b->n * 8u ? PI_ERR_INPUT : PI_OK;
-}
+#define PI_NAME coded_block_fast
+#define PI_T uint16_t
+#define PI_MARKERS 1
+#include "pinflate_loop.h"
+#undef PI_NAME
+#undef PI_T
+#undef PI_MARKERS
+#define PI_NAME coded_block_bytes
+#define PI_T uint8_t
+#define PI_MARKERS 0
+#include "pinflate_loop.h"
+#undef PI_NAME
+#undef PI_T
+#undef PI_MARKERS
 
 /* Is `bitpos` plausibly the start of a block?  0 no; 1 dynamic with a valid header; 2 stored with matching lengths;
  * 3 fixed. */
@@ -616,9 +453,11 @@ int64_t csh_deflate_find_block(const uint8_t *in, int64_t n_bytes, int64_t from_
 /* Decode from the block boundary `start_bit` up to the first block boundary at or behind `stop_bit`, or the end of the
  * final block.  out: `cap` symbols.  *end_bit: where it stopped; *n_out: symbols written; *final: 1 when the final block
  * was decoded (end_bit is then the bit behind it).  PI_OK / PI_ERR_*. */
-int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int64_t stop_bit, uint16_t *out, int64_t cap,
-                      int64_t *end_bit, int64_t *n_out, int32_t *final) {
+static int inflate_blocks(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int64_t stop_bit, void *out_any, int wide,
+                          int64_t cap, int64_t *end_bit, int64_t *n_out, int32_t *final) {
   const size_t n = (size_t)n_bytes;
+  uint16_t *out16 = wide ? (uint16_t *)out_any : NULL;
+  uint8_t *out8 = wide ? NULL : (uint8_t *)out_any;
   if (!g_fixed_ready) fixed_codes();
   huff_t *lit = (huff_t *)malloc(sizeof(huff_t)), *dist = (huff_t *)malloc(sizeof(huff_t));
   if (!lit || !dist) {
@@ -655,11 +494,15 @@ int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int
         rc = PI_ERR_SPACE;
         break;
       }
-      for (uint32_t i = 0; i < len; ++i) out[o + i] = in[at + i];
+      if (wide)
+        for (uint32_t i = 0; i < len; ++i) out16[o + i] = in[at + i];
+      else
+        memcpy(out8 + o, in + at, len);
       o += len;
       bits_init(&b, in, n, (at + len) * 8u);
     } else if (type == 1) {
-      rc = coded_block_fast(&b, &g_fixed_lit, &g_fixed_dist, out, (size_t)cap, &o);
+      rc = wide ? coded_block_fast(&b, &g_fixed_lit, &g_fixed_dist, out16, (size_t)cap, &o)
+                : coded_block_bytes(&b, &g_fixed_lit, &g_fixed_dist, out8, (size_t)cap, &o);
       if (rc) break;
     } else if (type == 2) {
       rc = dynamic_header(&b, lit, dist);
@@ -667,7 +510,7 @@ int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int
       huff_widen(lit);
       huff_widen_dist(dist);
       huff_combine(lit, dist);
-      rc = coded_block_fast(&b, lit, dist, out, (size_t)cap, &o);
+      rc = wide ? coded_block_fast(&b, lit, dist, out16, (size_t)cap, &o) : coded_block_bytes(&b, lit, dist, out8, (size_t)cap, &o);
       if (rc) break;
     } else {
       rc = PI_ERR_DATA;
@@ -681,6 +524,24 @@ int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int
   *n_out = (int64_t)o;
   *final = (rc == PI_OK && last) ? 1 : 0;
   return rc;
+}
+
+int csh_inflate_chunk(const uint8_t *in, int64_t n_bytes, int64_t start_bit, int64_t stop_bit, uint16_t *out, int64_t cap,
+                      int64_t *end_bit, int64_t *n_out, int32_t *final) {
+  return inflate_blocks(in, n_bytes, start_bit, stop_bit, out, 1, cap, end_bit, n_out, final);
+}
+
+/* A whole deflate stream from its first block (bit `start_bit`: behind a gzip member's header) to the end of its final
+ * block, as plain bytes: nothing precedes it, so no markers and no second pass.  out: `cap` bytes (the loop wants 320
+ * bytes of room in front of every step: PI_ERR_SPACE a little earlier than strictly needed).  *end_bit: the bit behind
+ * the final block (the member's trailer starts at the next byte boundary).  PI_OK only when the final block was
+ * decoded. */
+int csh_inflate_stream(const uint8_t *in, int64_t n_bytes, int64_t start_bit, uint8_t *out, int64_t cap, int64_t *end_bit,
+                       int64_t *n_out) {
+  int32_t final = 0;
+  const int rc = inflate_blocks(in, n_bytes, start_bit, INT64_MAX, out, 0, cap, end_bit, n_out, &final);
+  if (rc != PI_OK) return rc;
+  return final ? PI_OK : PI_ERR_INPUT;
 }
 
 /* symbols -> bytes.  `window`: the WINDOW bytes in front of the chunk (marker i stands for window[i]); NULL when
