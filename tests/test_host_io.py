@@ -772,3 +772,80 @@ def test_rank_shares_reproduce_the_one_process_block_stream(tmp_path, unpinned):
     single.write_bytes(gzip.compress(b"".join(recs2), 1))
     assert ranks.split_inputs([str(p1), str(single)], 2)[0] is None
     assert ranks._strip_option(["-A", "X", "--ranks", "4", "a", "--ranks=2", "b"], "--ranks") == ["-A", "X", "a", "b"]
+
+
+def test_member_decoder_in_byte_mode_equals_zlib_and_fails_safely():
+    """csh_inflate_stream (csrc/pinflate.c, the block loop of pinflate_loop.h instantiated for plain bytes): what a
+    multi-member file's members go through.  Same bytes as zlib for every block type and compressor setting; a buffer
+    that is too small says so and is never overrun; truncated input and starts in the middle of nowhere are errors."""
+    import ctypes as C
+    import random
+    import zlib
+    from cutseq_amd import build
+    H = C.CDLL(str(build.build_host()))
+    H.csh_inflate_stream.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    rng = random.Random(21)
+
+    def text(kind, n):
+        if kind == 0:
+            return bytes(rng.choice(b"ACGT") for _ in range(n))
+        if kind == 1:
+            return rng.randbytes(n)
+        if kind == 2:  # long runs: distances below eight, lengths up to 258
+            return (b"F" * rng.randrange(1, 600) + b"CG" * rng.randrange(1, 300) + bytes(rng.choice(b"ACGTN") for _ in range(50))) * max(1, n // 900)
+        return b"".join(b"@r%d/1\n" % i + bytes(rng.choice(b"ACGT") for _ in range(100)) + b"\n+\n" +
+                        bytes(rng.choice(b"FFFFFF:,#") for _ in range(100)) + b"\n" for i in range(n // 200 + 1))
+
+    end, got = C.c_int64(), C.c_int64()
+    cases = 0
+    for _ in range(40):
+        data = text(rng.randrange(4), rng.choice([0, 1, 7, 300, 5000, 70_000, 300_000]))
+        for level, strategy in ((1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (1, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (0, 0)):
+            c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+            raw = c.compress(data) + c.flush()
+            buf = np.frombuffer(raw + bytes(64), dtype=np.uint8).copy()
+            cap = len(data) + 400  # (the loop wants 320 bytes of room)
+            out = np.zeros(cap, dtype=np.uint8)
+            assert H.csh_inflate_stream(buf.ctypes.data, len(raw), 0, out.ctypes.data, cap, C.byref(end), C.byref(got)) == 0
+            assert out[:got.value].tobytes() == data and (end.value + 7) // 8 == len(raw)
+            cases += 1
+            if len(data) > 1000:
+                half = len(data) // 2
+                guard = np.full(half + 64, 0xAB, dtype=np.uint8)
+                assert H.csh_inflate_stream(buf.ctypes.data, len(raw), 0, guard.ctypes.data, half, C.byref(end), C.byref(got)) == -2
+                assert (guard[half:] == 0xAB).all()
+            if len(raw) > 50:
+                cut = np.frombuffer(raw[: len(raw) // 2] + bytes(64), dtype=np.uint8).copy()
+                assert H.csh_inflate_stream(cut.ctypes.data, len(raw) // 2, 0, out.ctypes.data, cap, C.byref(end), C.byref(got)) != 0
+                H.csh_inflate_stream(buf.ctypes.data, len(raw), rng.randrange(8, len(raw) * 4), out.ctypes.data, cap, C.byref(end), C.byref(got))  # any answer, no crash
+    assert cases == 280
+
+
+def test_multi_member_input_through_either_member_decoder(tmp_path, monkeypatch):
+    """GzipSource on a multi-member file: the host library's byte-mode decoder (default) and libdeflate
+    (CUTSEQ_OWN_INFLATE=0) hand out the same blocks; a damaged member raises with either."""
+    import random
+    from cutseq_amd import codec
+    rng = random.Random(4)
+    members = [b"".join(b"@m%d_%d\n" % (k, i) + bytes(rng.choice(b"ACGT") for _ in range(80)) + b"\n+\n" + b"F" * 80 + b"\n"
+                        for i in range(rng.randrange(1, 4000))) for k in range(12)]
+    named = b"\x1f\x8b\x08\x08\0\0\0\0\0\xffx.fq\0" + gzip.compress(members[0], 1)[10:]  # a header with a file name
+    blob = named + b"".join(gzip.compress(m, rng.choice([1, 6, 9])) for m in members[1:]) + gzip.compress(b"")
+    path = tmp_path / "multi.fq.gz"
+    pool = fastq._pool()
+
+    def read(data):
+        path.write_bytes(data)
+        src = codec.GzipSource(str(path), pool)
+        out = b"".join(bytes(memoryview(arr)[:n]) for arr, n in src.blocks())
+        src.close()
+        return out
+
+    want = b"".join(members)
+    for own in ("1", "0"):
+        monkeypatch.setenv("CUTSEQ_OWN_INFLATE", own)
+        assert read(blob) == want
+        for damage in (lambda b: b[:-28] + bytes([b[-28] ^ 0x40]) + b[-27:],                         # CRC-32 of the last full member (the empty one behind it is 20 bytes)
+                       lambda b: b[: len(b) // 2] + bytes([b[len(b) // 2] ^ 0xFF]) + b[len(b) // 2 + 1:]):  # deflate data in the middle
+            with pytest.raises(OSError):
+                read(damage(blob))
