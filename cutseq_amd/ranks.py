@@ -196,7 +196,7 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
             with open(path, "w") as fh:
                 json.dump(spec, fh)
             specs.append(spec)
-            env = dict(os.environ, CUTSEQ_DEVICES=str(devices[r % len(devices)]))
+            env = dict(os.environ, CUTSEQ_DEVICES=str(devices[r % len(devices)]), CUTSEQ_PROGRESS="0")  # (one Done line: the parent's)
             children.append(subprocess.Popen([sys.executable, "-m", "cutseq_amd.run"] + child_argv + ["--rank-spec", path], env=env))
         codes = [c.wait() for c in children]
         if any(codes):
@@ -215,6 +215,10 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
             devs += part["devices"]
         bin_names = list(args.demux[0]) if getattr(args, "demux", None) else None
         totals.update(stats=stats, devices=devs, bin_names=bin_names, seconds=time.perf_counter() - t0, ranks=world)
+        progress = report.Progress()
+        progress.t0 -= totals["seconds"]
+        progress.update(totals["in_pairs"])
+        progress.close()
         return totals
     except BaseException:
         for c in children:

@@ -196,3 +196,50 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
 def write_json(path: str, report: dict) -> None:
     with open(path, "w") as fh:
         fh.write(json.dumps(report, indent=2))
+
+
+class Progress:
+    """Counterpart of cutadapt's ``Progress()``, which the reference hands to ``runner.run`` unconditionally
+    (cutseq/run.py:473, 794): a status line on stderr while the run goes on and a ``Done`` line with reads, µs per read
+    and M reads per minute at its end (layout recalled from cutadapt's ``utils.Progress``).  The running line -- carriage
+    returns, one update per second -- is only drawn on a terminal; the final line is always written, as the reference's
+    is.  ``CUTSEQ_PROGRESS=0`` silences both."""
+
+    def __init__(self, stream=None):
+        import os
+        import sys
+        import threading
+        import time
+        self._time = time
+        self.stream = stream if stream is not None else sys.stderr
+        self.enabled = os.environ.get("CUTSEQ_PROGRESS", "1") != "0"
+        self.live = self.enabled and hasattr(self.stream, "isatty") and self.stream.isatty()
+        self.t0 = time.time()
+        self.last = self.t0
+        self.total = 0
+        self._lock = threading.Lock()
+        self._frames = 0
+
+    def _line(self, head: str, now: float) -> str:
+        elapsed = max(now - self.t0, 1e-9)
+        per_item = elapsed / self.total if self.total else 0.0
+        per_minute = self.total / elapsed * 60.0 / 1e6
+        h, rem = divmod(int(elapsed), 3600)
+        m, sec = divmod(rem, 60)
+        return f"{head:<10s} {h:02d}:{m:02d}:{sec:02d} {self.total:13,d} reads @ {per_item * 1e6:5.1F} µs/read; {per_minute:6.2F} M reads/minute"
+
+    def update(self, n: int) -> None:
+        with self._lock:
+            self.total += int(n)
+            now = self._time.time()
+            if self.live and now - self.last >= 1.0:
+                self.last = now
+                self._frames += 1
+                k = self._frames % 8
+                print("\r" + self._line("[" + "-" * k + "8<" + "-" * (7 - k) + "]", now), end="", file=self.stream, flush=True)
+
+    def close(self) -> None:
+        if not self.enabled:
+            return
+        with self._lock:
+            print(("\r" if self.live else "") + self._line("Done", self._time.time()), file=self.stream, flush=True)

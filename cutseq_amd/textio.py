@@ -662,9 +662,12 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
     budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk
     failure: List[BaseException] = []
 
+    progress = report.Progress()
+
     def emit(item: _Done):
         res = item.res
         totals["in_pairs"] += item.n
+        progress.update(item.n)
         if item.counts is not None:  # (demultiplexing: [0] stays 0, the barcodes' pairs are routes 3 ..)
             for q in range(len(item.counts)):
                 totals["routes"][q] += int(item.counts[q])
@@ -783,6 +786,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         totals["in_bp"][m] = sum(int(pair[m]["in_bp"]) for pair in stats)
         totals["out_bp"][m] = sum(int(pair[m]["out_bp"]) for pair in stats)
     totals["seconds"] = time.perf_counter() - t_start
+    progress.close()
     totals["bin_names"] = list(args.demux[0]) if n_bins else None
     totals["stats"] = stats
     totals["devices"] = devices

@@ -849,3 +849,25 @@ def test_multi_member_input_through_either_member_decoder(tmp_path, monkeypatch)
                        lambda b: b[: len(b) // 2] + bytes([b[len(b) // 2] ^ 0xFF]) + b[len(b) // 2 + 1:]):  # deflate data in the middle
             with pytest.raises(OSError):
                 read(damage(blob))
+
+
+def test_progress_writes_one_done_line_like_the_reference(monkeypatch):
+    """report.Progress: the reference hands cutadapt's Progress() to runner.run (cutseq/run.py:473, 794); off a terminal
+    only the final line appears."""
+    import io
+    from cutseq_amd import report
+    buf = io.StringIO()
+    p = report.Progress(buf)
+    p.t0 -= 5.0
+    p.update(3_000_000)
+    p.update(5_000_000)
+    p.close()
+    line = buf.getvalue()
+    assert line.count("\n") == 1 and "\r" not in line
+    assert line.startswith("Done") and "8,000,000 reads @" in line and "µs/read;" in line and line.rstrip().endswith("M reads/minute")
+    monkeypatch.setenv("CUTSEQ_PROGRESS", "0")
+    buf = io.StringIO()
+    p = report.Progress(buf)
+    p.update(10)
+    p.close()
+    assert buf.getvalue() == ""
