@@ -354,6 +354,7 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
     gz = [[(fh.gz if fh is not None else None) for fh in (group + [None])[:2]] for group in outs]
 
     totals = report.new_totals()
+    progress = report.Progress()
     t0 = time.perf_counter()
     pool = fastq._pool()
     max_finishing = fastq.pool_size() + 2  # chunks being formatted / compressed (about 90 MB each)
@@ -391,6 +392,7 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
                 while next_k in waiting:
                     _, chunk, (r1, cap2, r2) = waiting.pop(next_k)
                     next_k += 1
+                    progress.update(chunk.n)
                     fut = pool.submit(finish, chunk, r1, cap2, r2)
                     for route in range(len(outs)):
                         for m in range(2 if paired else 1):
@@ -456,6 +458,7 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
     fastq.PINNED.free_pinned()  # every chunk has been written and released
     stats = [w.stats for w in workers if w.stats is not None]
     totals["seconds"] = time.perf_counter() - t0
+    progress.close()
     totals["bin_names"] = list(args.demux[0]) if n_bins else None
     totals["stats"] = stats
     totals["devices"] = devices
