@@ -2,6 +2,7 @@
 """Headline benchmark: M read-pairs/s of the trimming kernels (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 25 --warmup 10
+    python bench.py --gpus N --steps K --warmup W        (spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -108,14 +109,50 @@ def replayed_counters(path: str, n: int):
     return pm, None
 
 
+def self_launch(n_ranks: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: N fresh child processes of this script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way torch.distributed.run sets them (the counterpart of the
+    reference's ``make_runner(cores=N)``, cutseq/run.py:436, 753).  The parent touches no GPU (children are started
+    with subprocess, nothing is re-exec'ed), relays the children's output -- rank 0 prints the JSON line -- and
+    returns non-zero as soon as any child does, stopping the others."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    code = 0
+    left = list(children)
+    while left:
+        for c in list(left):
+            rc = c.poll()
+            if rc is None:
+                continue
+            left.remove(c)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                for other in left:  # one rank failed: the others would wait at the barrier for ever
+                    other.terminate()
+        if left:
+            time.sleep(0.05)
+    return code
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process has made no GPU call yet and becomes the launcher
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the trimming engine has no CPU path")

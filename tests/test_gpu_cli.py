@@ -236,11 +236,13 @@ def test_cli_reads_of_any_length(tmp_path, monkeypatch):
     assert int(o1["stop"][700]) < 12100 and int(o1["flags"][700]) & 2  # the adapter inside the 12 kb read was found
 
 
-def test_bench_two_ranks_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(launcher):
     """bench.py's N > 1 path (one process per GPU, shard by global read index, no data-path collective) with two
     ranks on GPU 0 and gloo for the barrier (CUTSEQ_BENCH_REHEARSAL=1; RCCL wants one device per rank).  The CPU
     sample at N = 1 checks the device results against the oracle; here the two-rank run must report twice the
-    work of one rank and a positive rate."""
+    work of one rank and a positive rate.  Both launch forms: plain ``python bench.py --gpus 2`` (the script spawns
+    its own ranks, the way the driver starts --gpus 1) and under torch.distributed.run."""
     import os
     import socket
     import subprocess
@@ -250,9 +252,14 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, CUTSEQ_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(util.GOLDEN.parents[1] / "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--pairs", "300000"]
+    tail = [str(util.GOLDEN.parents[1] / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "300000"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+        for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+            env.pop(name, None)
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -81,3 +81,19 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert list(red) == [s1.n_reads, s1.out_bp, s1.op_matched[1], s2.n_reads, s2.out_bp, s2.qualtrim_bp]
     merged = shard.merge_stats([s1.as_dict(), s1.as_dict()])
     assert merged["n_reads"] == 2 * s1.n_reads and merged["op_matched"][1] == 2 * s1.op_matched[1]
+
+
+def test_bench_self_launch_spawns_ranks_and_relays_failure():
+    """``python bench.py --gpus 2`` with no launcher around it: the parent spawns one child per rank with the
+    torch.distributed.run environment and exits non-zero when a child does.  Without a GPU every child stops at
+    "bench.py needs an MI355X" -- which is exactly what shows that two ranks were started with WORLD_SIZE=2."""
+    import subprocess
+
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU by tests/test_gpu_cli.py::test_bench_two_ranks_rehearsal_on_one_gpu")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--pairs", "1000"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("needs an MI355X") >= 1, out.stderr[-1000:]
+    assert "does not match --gpus" not in out.stderr
