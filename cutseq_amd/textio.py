@@ -152,7 +152,12 @@ class TextReader(threading.Thread):
 
         def job(i):
             off = fill + i * _BLOCK
-            got = os.preadv(fd, [mv[off:off + _BLOCK]], pos + i * _BLOCK)
+            got = 0
+            while got < _BLOCK:  # a short read is not the end of the file (FUSE, network mounts): only 0 bytes is
+                more = os.preadv(fd, [mv[off + got:off + _BLOCK]], pos + i * _BLOCK + got)
+                if more <= 0:
+                    break
+                got += more
             return got, (int(L.csh_count_newlines(base + off, got)) if got else 0)
 
         pool = fastq._pool()
@@ -269,7 +274,12 @@ class TextReader(threading.Thread):
                         block.release()
                         return
                     continue
-                # end of input: what is left must be whole records (blank lines behind the last one are tolerated)
+                # End of input: what is left must be whole records; blank lines behind the last one are tolerated.
+                # The last NON-BLANK line decides: it is line 4k + 3 (a quality line: the record ends with it, the
+                # device takes the end of the text for its missing line end) or line 4k + 2 (a '+' line: the record
+                # has an empty read, "@id\n\n+\n\n", and its empty quality line is the first blank line behind it).
+                # Only whole blank lines beyond that are dropped -- stripping all trailing white space took the
+                # empty quality line with it and turned a valid file into "truncated".
                 end = fill
                 view = memoryview(buf)
                 while end > 0 and view[end - 1] in b"\n\r \t":
@@ -279,8 +289,24 @@ class TextReader(threading.Thread):
                     buf = None
                     self._put(None)
                     return
-                tail_lines = int(L.csh_count_newlines(buf.ctypes.data, end)) + 1  # the last line lost its line end above
-                if tail_lines % 4:
+                last = int(L.csh_count_newlines(buf.ctypes.data, end))  # index of the last non-blank line
+                if last % 4 == 3:
+                    tail_lines = last + 1
+                elif last % 4 == 2 and end < fill:
+                    # the '+' line's own line end, then the empty quality line (its '\n' is written if the file lacks it)
+                    tail = bytes(view[end:fill])  # white space only
+                    nl1 = tail.find(b"\n")
+                    if nl1 < 0:
+                        raise fastq.FastqFormatError(f"{self.path}: truncated FASTQ record at end of file")
+                    nl2 = tail.find(b"\n", nl1 + 1)
+                    if nl2 >= 0:
+                        end += nl2 + 1
+                    else:
+                        buf = self._room(buf, fill, 1)
+                        buf[fill] = 0x0A
+                        end = fill + 1
+                    tail_lines = last + 2
+                else:
                     raise fastq.FastqFormatError(f"{self.path}: truncated FASTQ record at end of file")
                 block = TextBlock(buf, end, tail_lines // 4, done)
                 buf = None

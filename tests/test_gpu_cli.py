@@ -77,6 +77,28 @@ def test_cli_single_end_rc_and_untrimmed(tmp_path):
     assert len(want["untrimmed"][0]) > 0
 
 
+@pytest.mark.parametrize("gz", [False, True])
+def test_cli_zero_length_final_record(tmp_path, gz):
+    """A file whose LAST record is empty ("@id\\n\\n+\\n\\n": dnaio reads it, already-trimmed inputs hold such records)
+    used to die with 'truncated FASTQ record at end of file' (textio.TextReader); with and without the
+    empty quality line's own line end, plain and gzip."""
+    rec = util.read_fastq_gz(R1, limit=200) + [(b"last 1:N:0:X", b"", b"")]
+    body = b"".join(b"@" + n + b"\n" + s + b"\n+\n" + q + b"\n" for n, s, q in rec)
+    batch = util.batch_from_records(rec)
+    st = planmod.CutadaptConfig()
+    st.min_length = 0
+    want = util.pyref_run(BUILDIN_ADAPTERS["TAKARAV3"], st, batch, [r[0] for r in rec])
+    want = b"".join(x[1] for x in want if x[0] == 0)
+    assert want.endswith(b"@last\n\n+\n\n")
+    for k, text in enumerate((body, body[:-1], body + b"\n\n")):
+        src = str(tmp_path / (f"in{k}.fq.gz" if gz else f"in{k}.fq"))
+        with open(src, "wb") as fh:
+            fh.write(gzip.compress(text, 1) if gz else text)
+        out = str(tmp_path / f"o{k}.fq")
+        cli.main([src, "-A", "TAKARAV3", "-m", "0", "-o", out, "-s", str(tmp_path / f"s{k}.fq")])
+        assert open(out, "rb").read() == want, k
+
+
 # ---------------------------------------------------------------- the runner beyond one chunk
 
 

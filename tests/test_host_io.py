@@ -723,6 +723,34 @@ def test_text_reader_cuts_blocks_of_whole_records(tmp_path, unpinned, container)
     assert _drain(textio.TextReader(str(empty), 7000)) == (b"", [])
 
 
+@pytest.mark.parametrize("gz", [False, True])
+@pytest.mark.parametrize("tail,blocks", [
+    (b"@e\n\n+\n\n", b"@e\n\n+\n\n"),            # a zero-length final record (already-trimmed inputs hold them)
+    (b"@e\n\n+\n", b"@e\n\n+\n\n"),               # ... whose empty quality line has no line end: one is supplied
+    (b"@e\n\n+\n\n\n\n", b"@e\n\n+\n\n"),         # ... with blank lines behind it: only whole blank lines go
+    (b"@e\r\n\r\n+\r\n\r\n", b"@e\r\n\r\n+\r\n\r\n"),
+    (b"@e\nAC\n+\nII\n\n \n", b"@e\nAC\n+\nII"),    # an ordinary last record with a blank tail
+])
+def test_text_reader_zero_length_final_record(tmp_path, unpinned, gz, tail, blocks):
+    """the end-of-input branch stripped ALL trailing white space before counting lines, so a file whose
+    last record is empty ("@id\\n\\n+\\n\\n", which dnaio reads and trimmed files contain) lost its quality line and
+    the run died with 'truncated FASTQ record'.  The last non-blank line decides now."""
+    from cutseq_amd import textio
+    head = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(10))
+    path = tmp_path / ("in.fq.gz" if gz else "in.fq")
+    path.write_bytes(gzip.compress(head + tail, 1) if gz else head + tail)
+    got, sizes = _drain(textio.TextReader(str(path), 7000))
+    assert sizes == [11]
+    assert got == head + blocks
+    # the same record in the MIDDLE of a file (blocks there are cut by newline count) and a '+' line with nothing behind it
+    path.write_bytes(gzip.compress(head + b"@e\n\n+\n\n" + head, 1) if gz else head + b"@e\n\n+\n\n" + head)
+    got, sizes = _drain(textio.TextReader(str(path), 7000))
+    assert sizes == [21] and got == (head + b"@e\n\n+\n\n" + head)[:-1]
+    path.write_bytes(gzip.compress(head + b"@e\n\n+", 1) if gz else head + b"@e\n\n+")
+    with pytest.raises(fastq.FastqFormatError):
+        _drain(textio.TextReader(str(path), 7000))
+
+
 def test_stream_writer_orders_pieces_and_releases_buffers(tmp_path, unpinned):
     from cutseq_amd import textio
     rng = np.random.default_rng(1)
