@@ -9,7 +9,7 @@ from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 SRC = HERE / "csrc" / "cutseq_hip.hip"
-DEPS = [SRC, HERE / "csrc" / "trim_kernel.hip.inc", HERE / "csrc" / "finish_kernel.hip.inc", HERE / "csrc" / "long_kernel.hip.inc",
+DEPS = [SRC, HERE / "csrc" / "trim_kernel.hip.inc", HERE / "csrc" / "long_kernel.hip.inc",
         HERE / "csrc" / "text_kernels.hip.inc", HERE / "csrc" / "deflate_kernels.hip.inc",
         HERE.parent / "include" / "cutseq_hip.h"]
 OUT = HERE / "libcutseq_hip.so"
@@ -20,7 +20,7 @@ def kernel_source_hash() -> str:
     it was collected on the kernels it is running (tools/summarize_pmc.py)."""
     import hashlib
     h = hashlib.sha256()
-    for path in (HERE / "csrc" / "trim_kernel.hip.inc", HERE / "csrc" / "finish_kernel.hip.inc", SRC):
+    for path in (HERE / "csrc" / "trim_kernel.hip.inc", SRC):
         # (the text kernels are not what the counters measure)
         h.update(path.read_bytes())
     return h.hexdigest()

@@ -19,7 +19,6 @@
 
 #include "../../include/cutseq_hip.h"
 #include "trim_kernel.hip.inc"
-#include "finish_kernel.hip.inc"
 #include "long_kernel.hip.inc"
 #include "text_kernels.hip.inc"
 #include "deflate_kernels.hip.inc"
@@ -68,7 +67,6 @@ struct Slot {
 struct Lane {
   uint32_t *d_counters = nullptr;
   void *d_defer[2] = {nullptr, nullptr};  // per mate: queue of deferred reads (kDeferRecordBytes each)
-  void *d_carry[2] = {nullptr, nullptr};  // per mate: carry records of the split form (16 bytes per read)
   uint32_t defer_capacity = 0;            // records per mate
   hipEvent_t scanned = nullptr;           // scan kernel finished (what the resolve stream waits for)
   hipEvent_t done = nullptr;              // resolve kernel finished
@@ -136,9 +134,6 @@ struct cs_engine {
   uint32_t n_table_ops = 1;
   uint32_t col_dwords = 0;   // per-wave DP scratch the plan needs (resolve kernel)
   uint32_t waves_per_simd[2] = {4, 4};  // scan / resolve kernel, from their register counts
-  // split form: the scan kernel stops behind the leading Myers adapter ops, the finish kernel walks the rest
-  bool lean = false;
-  uint32_t lean_ops[2] = {0, 0};
   bool long_demux = false;  // a CS_OP_DEMUX op with the barcodes' own ops (cs_plan_set_demux_ops)
   int demux_mate = -1;      // 0 / 1: the mate whose chain holds a CS_OP_DEMUX op
   uint32_t demux_bins = 0;  // ... and how many barcodes its table names
@@ -255,7 +250,7 @@ const void *kernel_of(const cs_engine *eng) {
 }
 const void *kernel_for(const cs_engine *eng, int mode) {
   if (mode == csdev::MODE_RESOLVE) return kernel_of<csdev::MODE_RESOLVE>(eng);
-  return eng->lean ? kernel_of<csdev::MODE_LEAN>(eng) : kernel_of<csdev::MODE_SCAN>(eng);
+  return kernel_of<csdev::MODE_SCAN>(eng);
 }
 
 int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
@@ -269,7 +264,6 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   g.tile_rows = kTileRows;
   g.col_dwords = 0;
   uint32_t table_ops = eng->n_table_ops;
-  if (mode == csdev::MODE_SCAN && eng->lean) table_ops = eng->lean_ops[0] > eng->lean_ops[1] ? eng->lean_ops[0] : eng->lean_ops[1];
   uint32_t words = kTileRows * g.lds_stride_dw + table_ops * (csdev::kEqTableBytes / 4 + csdev::kFnibDwords) +
                    csdev::kStatWords +
                    96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
@@ -340,14 +334,11 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
       if (l.used) HIP_TRY(hipEventSynchronize(l.done));  // an earlier launch may still be reading the old queue
       for (int m = 0; m < 2; ++m) {
         if (l.d_defer[m]) (void)hipFree(l.d_defer[m]);
-        if (l.d_carry[m]) (void)hipFree(l.d_carry[m]);
-        l.d_defer[m] = l.d_carry[m] = nullptr;
+        l.d_defer[m] = nullptr;
       }
       l.defer_capacity = 0;
-      for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m) {
+      for (uint32_t m = 0; m < (eng->paired ? 2u : 1u); ++m)
         HIP_TRY(hipMalloc(&l.d_defer[m], (size_t)cap * kDeferRecordBytes));
-        if (eng->lean) HIP_TRY(hipMalloc(&l.d_carry[m], (size_t)cap * sizeof(uint4)));
-      }
       l.defer_capacity = cap;
     }
   }
@@ -363,10 +354,6 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   a.n_table_ops = eng->n_table_ops;
   a.batch_knob = eng->knob_batch;
   a.gate = gate;
-  for (int m = 0; m < 2; ++m) {
-    a.carry[m] = reinterpret_cast<uint4 *>(ln.d_carry[m]);
-    a.lean_ops[m] = eng->lean_ops[m];
-  }
   for (int mode = 0; mode < 2; ++mode)
     if (g[mode].lds_bytes > eng->max_dynamic_lds[mode]) {
       HIP_TRY(hipFuncSetAttribute(kernel_for(eng, mode), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g[mode].lds_bytes));
@@ -414,40 +401,12 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
     a.lds_stride_dw = g[mode].lds_stride_dw;
     a.col_dwords = g[mode].col_dwords;
     a.n_table_ops = eng->n_table_ops;
-    if (mode == csdev::MODE_SCAN && eng->lean) a.n_table_ops = eng->lean_ops[0] > eng->lean_ops[1] ? eng->lean_ops[0] : eng->lean_ops[1];
     void *kargs[] = {&a};
     hipStream_t st = mode == csdev::MODE_SCAN ? stream : rstream;
     if (mode == csdev::MODE_RESOLVE && rstream != stream) {
       // (one marker on the scan stream serves the timing and the hand-over: ev_mid when the call is timed)
       if (!time_it) HIP_TRY(hipEventRecord(ln.scanned, stream));
       HIP_TRY(hipStreamWaitEvent(rstream, time_it ? ln.ev_mid : ln.scanned, 0));
-    }
-    if (mode == csdev::MODE_RESOLVE && eng->lean) {
-      // split form: the rest of the chain for every read the scan kernel carried over, in front of the resolve kernel
-      // (it may add reads of its own to the queue)
-      csdev::FinishArgs fa;
-      memset(&fa, 0, sizeof fa);
-      for (uint32_t m = 0; m < mates; ++m) {
-        fa.mate[m] = a.mate[m];
-        fa.carry[m] = a.carry[m];
-        fa.first_op[m] = eng->lean_ops[m];
-        fa.defer[m] = a.defer[m];
-      }
-      fa.stats = a.stats;
-      fa.n_reads = n_reads;
-      fa.stride_dw = a.stride_dw;
-      fa.plan_slot = a.plan_slot;
-      fa.defer_count = a.defer_count;
-      fa.gate = gate;
-      uint32_t fgx = (n_tiles + 3u) / 4u;
-      const uint32_t fcap = (uint32_t)eng->n_cus * 8u / mates;
-      if (fgx > fcap) fgx = fcap;
-      if (fgx < 1) fgx = 1;
-      void *fargs[] = {&fa};
-      const void *fk = eng->coded ? reinterpret_cast<const void *>(csdev::finish_kernel<true>)
-                                  : reinterpret_cast<const void *>(csdev::finish_kernel<false>);
-      HIP_TRY(hipLaunchKernel(fk, dim3(fgx, mates, 1), dim3(256, 1, 1), fargs, 0, st));
-      HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipLaunchKernel(kernel_for(eng, mode), dim3(gx[mode], mates, 1), dim3(kTileRows, 1, 1), kargs,
                             g[mode].lds_bytes, st));
@@ -546,6 +505,44 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
         for (int idx = 0; idx < mm && idx < 32; ++idx)
           d.fnib[idx >> 3] |= (uint32_t)((d.op.seq[d.op.reversed ? mm - 1 - idx : idx] >> 3) & 7u) << (4 * (idx & 7));
     }
+  // The pair that opens the reference's chains (cutseq/run.py:332-355, 544-590): an existence-only 5' op at the head
+  // of the chain with a forward, free-ended Myers-32 op right behind it -> one merged forward walk in the scan kernel
+  // (trim_kernel.hip.inc, myers_pair).  CUTSEQ_PAIR=0 keeps the two scans apart.
+  {
+    const char *env = getenv("CUTSEQ_PAIR");
+    const bool allow = coded && !(env && atoi(env) == 0);
+    for (int m = 0; m < 2; ++m) {
+      if (!allow || cnt[m] < 2) continue;
+      csdev::DevOp &a = p->host.ops[m][0];
+      const csdev::DevOp &b = p->host.ops[m][1];
+      const int ma = a.op.m, ka = a.op.k, mo = a.op.min_overlap;
+      const bool ends_free = (b.op.align_flags & (CS_QUERY_START | CS_QUERY_STOP)) == (CS_QUERY_START | CS_QUERY_STOP);
+      if (!a.exists_only || a.op.kind != CS_OP_ADAPTER || b.op.kind != CS_OP_ADAPTER || b.exists_only ||
+          b.filter_mode != csdev::FILTER_MYERS32 || b.op.reversed || !ends_free || b.op.shortcut != CS_SHORTCUT_NONE ||
+          ma + ka > 31 || ka > 14)
+        continue;
+      a.pair_next = 1;
+      for (int ent = 0; ent < 4; ++ent) {
+        const int which = (ent == 0) ? 0 : (ent == 1) ? 1 : (ent == 2) ? 3 : 2;  // sel 2 = T, sel 3 = G
+        uint32_t fwd = 0;
+        for (int i = 0; i < ma; ++i)
+          if ((a.peq[which] >> (ma - 1 - i)) & 1ull) fwd |= 1u << i;  // a.op.seq holds the REVERSED adapter
+        a.eq_fwd[ent] = fwd << (32 - ma);
+      }
+      // T(j): the largest thr[i] over suffix lengths i in [min_overlap, m] that a candidate ending in column j can
+      // have (|i - j| <= thr[i]: an alignment of cost c moves at most c columns off the diagonal); none: -1
+      for (int j = 1; j <= 32; ++j) {
+        int best = -1;
+        if (j > ma + ka) best = ka;
+        else
+          for (int i = mo; i <= ma; ++i) {
+            const int d = i > j ? i - j : j - i;
+            if (d <= (int)a.op.thr[i] && (int)a.op.thr[i] > best) best = a.op.thr[i];
+          }
+        a.pair_tn[(j - 1) >> 3] |= (uint32_t)(best + 1) << (4 * ((j - 1) & 7));
+      }
+    }
+  }
   *out = p;
   return CS_OK;
 }
@@ -788,7 +785,6 @@ void cs_engine_destroy(cs_engine *eng) {
     if (ln.d_counters) (void)hipFree(ln.d_counters);
     for (int m = 0; m < 2; ++m) {
       if (ln.d_defer[m]) (void)hipFree(ln.d_defer[m]);
-      if (ln.d_carry[m]) (void)hipFree(ln.d_carry[m]);
     }
     for (hipEvent_t ev : {ln.scanned, ln.done, ln.ev_start, ln.ev_mid, ln.ev_stop})
       if (ev) (void)hipEventDestroy(ev);
@@ -845,31 +841,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
       const uint32_t need = (d.acgt_only && d.op.m <= 32) ? 16u * (d.op.m + 1u) : 2u * (d.op.m + 1u);
       if (need > eng->col_dwords) eng->col_dwords = need;
     }
-  // Split form (profiles/r03_lean_split.md): possible when the chain is [Myers adapter ops]
-  // [cuts / demultiplexing / homopolymer ops / quality trimming], which every chain cutseq/run.py compiles is.
-  // Measured SLOWER than the fused scan kernel (the finish kernel's HBM round trips cost more than the scan kernel
-  // gains), so it is opt-in: CUTSEQ_LEAN=1.  The parity suite runs the chain presets through it as well.
-  {
-    bool ok = plan->host.params.use_filter != 0;
-    for (int mt = 0; mt < 2 && ok; ++mt) {
-      const int n = plan->host.n_ops[mt];
-      int lead = 0;
-      while (lead < n && plan->host.ops[mt][lead].op.kind == CS_OP_ADAPTER &&
-             (plan->host.ops[mt][lead].filter_mode == csdev::FILTER_MYERS32 ||
-              plan->host.ops[mt][lead].filter_mode == csdev::FILTER_MYERS64))
-        ++lead;
-      eng->lean_ops[mt] = (uint32_t)lead;
-      for (int i = lead; i < n && ok; ++i) {
-        const csdev::DevOp &d = plan->host.ops[mt][i];
-        if (d.op.kind == CS_OP_ADAPTER)
-          ok = (d.filter_mode == csdev::FILTER_POLY_TAIL || d.filter_mode == csdev::FILTER_POLY_HEAD) && d.op.m <= 128;
-      }
-      if (n > 0 && (lead == 0 || lead == n)) ok = false;  // nothing to split off / nothing left behind the scans
-    }
-    const char *env = getenv("CUTSEQ_LEAN");
-    eng->lean = ok && env && atoi(env) == 1 && !has_long_demux;
-    eng->long_demux = has_long_demux;
-  }
+  eng->long_demux = has_long_demux;
   eng->max_reads = max_reads;
   eng->max_stride = max_stride;
 #define ENG_TRY(expr)                                                                     \

@@ -519,26 +519,3 @@ def test_hits_that_settle_in_the_filter_stress(seed):
             tie = rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION])
             tp = one_adapter_plan(seq, rate, mo, WHERE[where], remove, rightmost, 0, rule, True, tie)
             run_both(tp, batch, threads=8)
-
-
-@pytest.mark.parametrize("name,flags,paired", [c for c in CHAIN_CASES if not c[1].get("shortcut")])
-def test_split_form_lean_scan_plus_finish_kernel(name, flags, paired, monkeypatch):
-    """CUTSEQ_LEAN=1: the scan kernel stops behind the leading Myers adapter ops and a finish kernel walks the rest of
-    the chain from carry records (measured slower than the fused form, profiles/r03_lean_split.md, hence opt-in) --
-    same results, same statistics as the oracle for every preset x flag combination."""
-    monkeypatch.setenv("CUTSEQ_LEAN", "1")
-    scheme = BUILDIN_ADAPTERS.get(name, name)
-    st = planmod.CutadaptConfig()
-    for k, v in flags.items():
-        setattr(st, k, v)
-    batch = synth.generate_pairs(20_000, 150, scheme, seed=23, chunk_index=len(name), single_end=not paired,
-                                 poly_fraction=0.2, art5_fraction=0.02, indel_frac=0.1)
-    rng = np.random.default_rng(5)
-    cut = rng.random(batch.n) < 0.05
-    batch.len1[cut] = rng.integers(0, 150, size=int(cut.sum())).astype(np.uint16)
-    # a few reads that start with a long T run / end with a long A run: the homopolymer ops leave their closed form
-    for i in range(0, 400, 2):
-        batch.seq1[i, :120] = ord("T")
-        batch.seq1[i + 1, 20:150] = ord("A")
-    tp = util.compile_plan(scheme, st, paired, untrimmed_requested="INLINE" in name)
-    run_both(tp, batch, threads=8)
