@@ -70,7 +70,7 @@ summary = {
     "kernel_source_sha256": kernel_source_hash(),
     "measured_clock_hz": clock_hz,
     "measured_clock_source": clock_src,
-    "command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 "
+    "command": "rocprofv3 --pmc <counter set> --output-format csv -- python3 bench.py --steps 20 --warmup 10 --cpu-sample 0 "
                "--no-copy-probe (one pass per counter set of at most three SQ counters: tools/pmc.sh)",
     "kernels": {"scan": "csdev::trim_kernel<true,false,0>", "resolve": "csdev::trim_kernel<true,false,1>"},
     "pairs_per_launch": pairs,
