@@ -40,7 +40,20 @@ def expected(scheme, flags, paired, untrimmed_requested=False):
     return streams
 
 
-def test_cli_paired_takarav3(tmp_path, capsys):
+# Every switch the product reads from the environment gets the command line run through it:
+# the host parser / formatter instead of the text path, the scan kernel without the merged adapter-pair walk and without
+# the existence-only 5' scan, gzip outputs deflated on the host instead of on the device.
+SWITCHES = ["", "CUTSEQ_TEXT_PATH=0", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_GPU_DEFLATE=0"]
+
+
+@pytest.fixture(params=SWITCHES)
+def switch(request, monkeypatch):
+    if request.param:
+        monkeypatch.setenv(*request.param.split("="))
+    return request.param
+
+
+def test_cli_paired_takarav3(tmp_path, capsys, switch):
     prefix = str(tmp_path / "out")
     cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", prefix, "--json-file", str(tmp_path / "r.json"), R1, R2])
     want = expected(BUILDIN_ADAPTERS["TAKARAV3"], {"trim_polyA": True}, True)
@@ -66,7 +79,7 @@ def test_cli_paired_auto_rc_swaps_outputs(tmp_path):
     assert gunzip(s1) == want["short"][0] and gunzip(s2) == want["short"][1]
 
 
-def test_cli_single_end_rc_and_untrimmed(tmp_path):
+def test_cli_single_end_rc_and_untrimmed(tmp_path, switch):
     out, short, untr = (str(tmp_path / f"{n}.fastq.gz") for n in ("o", "s", "u"))
     scheme = "ACACGACGCTCTTCCGATCT(GGG)NNN<XXXAGATCGGAAGAGCACACGTC"
     cli.main([R1, "-a", scheme, "--auto-rc", "--ensure-inline-barcode", "--trim-polyA", "-o", out, "-s", short, "-u", untr])

@@ -255,7 +255,8 @@ def test_demux_table_matches_the_oracle_on_every_prefix():
     assert np.array_equal((op.table & 0x4000) != 0, n_match > 1)
 
 
-def test_cli_demultiplexes_like_independent_runs(tmp_path, monkeypatch):
+@pytest.mark.parametrize("switch", ["", "CUTSEQ_TEXT_PATH=0", "CUTSEQ_GPU_DEFLATE=0"])
+def test_cli_demultiplexes_like_independent_runs(tmp_path, monkeypatch, switch):
     """cutseq --demux-barcodes through the whole host path (two engines, several chunks): every barcode's
     trimmed files hold exactly what an --ensure-inline-barcode run with that one barcode would have written
     to its trimmed files; the untrimmed files hold the pairs no barcode claims."""
@@ -281,6 +282,8 @@ def test_cli_demultiplexes_like_independent_runs(tmp_path, monkeypatch):
     table.write_text("# name\tsequence\n" + "".join(f"{a}\t{b}\n" for a, b in zip(names, codes)))
     monkeypatch.setenv("CUTSEQ_DEVICES", "0,0")
     monkeypatch.setenv("CUTSEQ_CHUNK_READS", "6000")
+    if switch:  # (the host parser / formatter; gzip members deflated on the host)
+        monkeypatch.setenv(*switch.split("="))
     prefix = str(tmp_path / "dm")
     cli.main(["-a", scheme_with(codes[0]), "--demux-barcodes", str(table), "-O", prefix, "--json-file",
               str(tmp_path / "r.json"), in1, in2])

@@ -165,8 +165,65 @@ def test_poly_runs_with_scattered_errors(where, base, rule):
 
 
 @pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("anywhere", [False, True])
+def test_leading_adapter_pair_in_one_walk(rule, anywhere, monkeypatch):
+    """The scan kernel walks the chain's first two ops -- RightmostFrontAdapter, then BackAdapter (cutseq/run.py:332-355,
+    544-590) -- in ONE forward pass (myers_pair): the 5' op as a forward existence test (full-length occurrences anywhere,
+    adapter suffixes of at least min_overlap bases at the read's start), the 3' op as its exact filter.  Random adapter
+    pairs, overlaps and rates; reads built around partial and damaged copies of BOTH adapters at both ends, short
+    reads (tail columns inside the test's first groups), soft-masked stretches, the 3' op with ANYWHERE flags
+    (--force-anywhere).  Checked against the oracle, and the same batch with the merged walk switched off."""
+    rng = random.Random(977 + rule + 2 * anywhere)
+    for trial in range(10):
+        alpha = rng.choice(["ACGT", "ACGT", "ACGTN", "AC"])
+        m5, m3 = rng.choice([8, 12, 16, 20, 24, 26]), rng.choice([5, 13, 20, 28, 32])
+        p5 = util.random_dna(rng, m5, alpha.replace("N", ""))
+        p3 = util.random_dna(rng, m3, alpha.replace("N", ""))
+        rate5, rate3 = rng.choice([0.0, 0.1, 0.2]), rng.choice([0.0, 0.1, 0.2, 0.3])
+        mo5, mo3 = rng.randint(1, m5), rng.randint(1, min(m3, 10))
+        reads = []
+        for _ in range(3000):
+            style = rng.random()
+            body = util.random_dna(rng, rng.choice([0, 3, 10, 40, 90, 130]), alpha)
+            if style < 0.35:  # a suffix of the 5' adapter at the very start, damaged, then the insert
+                cut = rng.randint(0, m5)
+                head = util.mutate(rng, p5[cut:], rng.choice([0, 0, 1, 2, 3]), alpha)
+                s = head + body
+            elif style < 0.5:  # the whole 5' adapter somewhere inside
+                s = util.random_dna(rng, rng.randint(0, 30), alpha) + util.mutate(rng, p5, rng.choice([0, 1, 2, 5]), alpha) + body
+            else:
+                s = body
+            tail = rng.random()
+            if tail < 0.4:  # read-through into the 3' adapter
+                s += util.mutate(rng, p3, rng.choice([0, 0, 1, 2, 4]), alpha) + util.random_dna(rng, rng.choice([0, 5, 30]), alpha)
+            elif tail < 0.6:  # ... only its first bases fit
+                s += util.mutate(rng, p3[: rng.randint(1, m3)], rng.choice([0, 0, 1]), alpha)
+            s = s[: rng.choice([7, 15, 23, 31, 33, 150, 150, 150])]
+            reads.append((s, "I" * len(s)))
+        batch = util.batch_from_reads(reads)
+        util.soft_mask(batch, 0.1, seed=trial)
+        ops = [planmod.AdapterOp("p5", p5[::-1], rate5, mo5, WHERE["BACK"], abi.CS_REMOVE_BEFORE, rightmost=True,
+                                 match_flag=abi.CS_F_ADAPTER5),
+               planmod.AdapterOp("p3", p3, rate3, mo3, WHERE["ANYWHERE" if anywhere else "BACK"], abi.CS_REMOVE_AFTER,
+                                 match_flag=abi.CS_F_ADAPTER3)]
+        tp = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                              select_rule=rule, use_filter=True, indel_tie=rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION]))
+        g_pair, _ = run_both(tp, batch)
+        with monkeypatch.context() as mp:
+            mp.setenv("CUTSEQ_PAIR", "0")
+            g_apart, _ = run_both(tp, batch)
+        assert np.array_equal(g_pair, g_apart)
+
+
+@pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0"])
+@pytest.mark.parametrize("rule", [0, 1])
 @pytest.mark.parametrize("name,flags,paired", CHAIN_CASES)
-def test_chain_presets(name, flags, paired, rule):
+def test_chain_presets(name, flags, paired, rule, switch, monkeypatch):
+    """Every preset x flag chain; also with the merged walk of the leading adapter pair switched off (CUTSEQ_PAIR=0:
+    existence-only 5' scan + exact 3' filter apart) and with the existence-only scan off as well (CUTSEQ_EXISTS=0:
+    the exact filter for every op) -- the switches are read when the plan is created."""
+    if switch:
+        monkeypatch.setenv(*switch.split("="))
     scheme = BUILDIN_ADAPTERS.get(name, name)
     st = planmod.CutadaptConfig()
     for k, v in flags.items():
