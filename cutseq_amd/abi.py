@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-CS_ABI_VERSION = 5
+CS_ABI_VERSION = 6
 CS_MAX_ADAPTER = 128
 CS_MAX_OPS = 24
 CS_MAX_STRIDE = 1536
@@ -144,7 +144,8 @@ class cs_text_params(C.Structure):
         ("suffix1", C.c_char_p * 2),
         ("suffix2", C.c_char_p * 2),
         ("n_bins", C.c_uint32),
-        ("_reserved", C.c_uint32),
+        ("fasta_out", C.c_uint8),
+        ("_reserved", C.c_uint8 * 3),
     ]
 
 

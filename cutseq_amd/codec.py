@@ -17,6 +17,7 @@ import ctypes as C
 import mmap
 import os
 import struct
+import sys
 import threading
 import zlib
 from typing import Iterator
@@ -691,3 +692,217 @@ class GzipSource:
 def is_gzip(path: str) -> bool:
     with open(path, "rb") as fh:
         return fh.read(2) == b"\x1f\x8b"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other containers xopen gives the reference for nothing (cutseq/run.py:434, 437, 751, 754: InputPaths /
+# OutputFiles): bzip2, xz, zstandard (where a binding is importable) and "-" for standard input / output.  None of
+# them is a fast path -- the stdlib codecs run on one thread -- they feed the same block reader / ordered writers.
+
+_MAGIC = {b"\x1f\x8b": "gzip", b"BZh": "bz2", b"\xfd7zXZ\x00": "xz", b"\x28\xb5\x2f\xfd": "zst"}
+STREAM_BLOCK = 4 << 20
+
+
+def container_of_magic(head: bytes) -> str:
+    for magic, name in _MAGIC.items():
+        if head.startswith(magic):
+            return name
+    return "plain"
+
+
+def container_of_name(path: str) -> str:
+    """Output side: xopen goes by the file name's extension."""
+    low = path.lower()
+    for ext, name in ((".gz", "gzip"), (".bz2", "bz2"), (".xz", "xz"), (".zst", "zst")):
+        if low.endswith(ext):
+            return name
+    return "plain"
+
+
+def _zstd():
+    try:
+        import zstandard  # noqa: PLC0415
+        return zstandard
+    except ImportError:
+        raise ValueError("zstandard (.zst) files need the 'zstandard' Python module, which is not installed") from None
+
+
+def open_decoder(raw, container: str):
+    """A binary file object with the decompressed bytes of ``raw`` (a binary file object)."""
+    if container == "plain":
+        return raw
+    if container == "gzip":
+        import gzip
+        return gzip.GzipFile(fileobj=raw, mode="rb")
+    if container == "bz2":
+        import bz2
+        return bz2.BZ2File(raw, "rb")
+    if container == "xz":
+        import lzma
+        return lzma.LZMAFile(raw, "rb")
+    if container == "zst":
+        return _zstd().ZstdDecompressor().stream_reader(raw, read_across_frames=True)
+    raise ValueError(container)
+
+
+def make_compressor(container: str, level: int = 1):
+    """-> (compress(bytes-like) -> bytes, flush() -> bytes) for a sequential output stream."""
+    if container == "bz2":
+        import bz2
+        c = bz2.BZ2Compressor(max(1, min(9, level)))
+        return c.compress, c.flush
+    if container == "xz":
+        import lzma
+        c = lzma.LZMACompressor(preset=max(0, min(9, level)))
+        return c.compress, c.flush
+    if container == "zst":
+        c = _zstd().ZstdCompressor(level=level).compressobj()
+        return c.compress, c.flush
+    raise ValueError(container)
+
+
+class StreamSource:
+    """Blocks of decompressed text from a sequential reader: standard input, bzip2 / xz / zstandard files, and plain
+    or gzip files when a wrapper (FASTA) needs the bytes in order.  Same face as :class:`GzipSource`."""
+
+    def __init__(self, fileobj, take=_np_take, give=_np_give, owner=None):
+        self.f, self.take, self.give, self.owner = fileobj, take, give, owner
+
+    def side(self, arr):
+        return None
+
+    def close(self):
+        for f in (self.f, self.owner):
+            if f is not None and f is not sys.stdin.buffer:
+                try:
+                    f.close()
+                except Exception:  # noqa: BLE001
+                    pass
+
+    def blocks(self, start: int = 0) -> Iterator[tuple]:
+        assert start == 0, "a sequential stream has no entry points"
+        while True:
+            arr = self.take(STREAM_BLOCK)
+            mv = memoryview(arr)[:STREAM_BLOCK]
+            got = 0
+            while got < STREAM_BLOCK:
+                n = self.f.readinto(mv[got:])
+                if not n:
+                    break
+                got += n
+            if got == 0:
+                self.give(arr)
+                return
+            yield arr, got
+            if got < STREAM_BLOCK:
+                return
+
+
+class _Peeked:
+    """A binary reader with some bytes already taken off its front (sniffing standard input)."""
+
+    def __init__(self, head: bytes, rest):
+        self.head, self.rest = head, rest
+
+    def readinto(self, b) -> int:
+        if self.head:
+            n = min(len(b), len(self.head))
+            b[:n] = self.head[:n]
+            self.head = self.head[n:]
+            return n
+        return self.rest.readinto(b)
+
+    def read(self, n: int = -1) -> bytes:
+        if self.head:
+            out, self.head = (self.head, b"") if n < 0 or n >= len(self.head) else (self.head[:n], self.head[n:])
+            if n < 0:
+                return out + self.rest.read()
+            return out
+        return self.rest.read(n)
+
+    def readable(self):
+        return True
+
+    def close(self):
+        pass
+
+    @property
+    def closed(self):
+        return False
+
+    def seekable(self):
+        return False
+
+    def flush(self):
+        pass
+
+
+def sniff_input(path: str):
+    """-> (container, first byte of the TEXT behind leading white space, opener) where ``opener()`` gives a fresh binary
+    reader of the decompressed text.  ``path`` "-" is standard input (compression recognised by its magic bytes, as for
+    files)."""
+    if path == "-":
+        raw = sys.stdin.buffer
+        head = raw.read(8) or b""
+        container = container_of_magic(head)
+        peeked = _Peeked(head, raw)
+        dec = open_decoder(peeked, container)
+        text = dec.read(65536) or b""
+        first = text.lstrip()[:1]
+        stream = _Peeked(text, dec)
+        return container, first, (lambda: stream)
+    with open(path, "rb") as fh:
+        head = fh.read(8)
+    container = container_of_magic(head)
+
+    def opener():
+        return open_decoder(open(path, "rb"), container)
+
+    with opener() as dec:
+        text = dec.read(65536) or b""
+    return container, text.lstrip()[:1], opener
+
+
+class FastaSource:
+    """FASTA text re-shaped into four-line records on its way in (csh_fasta_to_fastq in csrc/cutseq_host.c: names and
+    joined sequence lines as they are, a quality line no cutoff trims) -- the device parses one record shape."""
+
+    def __init__(self, inner, convert, take=_np_take, give=_np_give, label="input"):
+        self.inner, self.convert, self.take, self.give, self.label = inner, convert, take, give, label
+
+    def side(self, arr):
+        return None
+
+    def close(self):
+        self.inner.close()
+
+    def blocks(self, start: int = 0) -> Iterator[tuple]:
+        carry = b""
+        line0 = 0
+        gen = self.inner.blocks(start)
+        done = False
+        while not done:
+            item = next(gen, None)
+            if item is None:
+                done = True
+                data = carry
+            else:
+                arr, nbytes = item
+                data = carry + bytes(memoryview(arr)[:nbytes])
+                self.give(arr)
+            if not data and done:
+                break
+            out = self.take(3 * len(data) + 64)
+            produced, consumed, err_line = self.convert(data, out, done)
+            if produced == -2:
+                self.give(out)
+                raise ValueError(f"{self.label}: FASTA format error in line {line0 + err_line}: expected '>' at the start of a record")
+            if produced < 0:
+                self.give(out)
+                raise MemoryError("FASTA conversion buffer too small")
+            line0 += data[:consumed].count(b"\n")
+            carry = data[consumed:]
+            if produced:
+                yield out, produced
+            else:
+                self.give(out)

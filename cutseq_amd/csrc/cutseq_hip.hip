@@ -1309,6 +1309,7 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
   t->tp.has_umi = params->has_umi ? 1 : 0;
   t->tp.untrimmed_filter = params->untrimmed_filter ? 1 : 0;
   t->tp.reverse_complement = params->reverse_complement ? 1 : 0;
+  t->tp.fasta_out = params->fasta_out ? 1 : 0;
   t->tp.flag_too_short = CS_F_TOO_SHORT;
   t->tp.flag_untrimmed = CS_F_UNTRIMMED;
   const char *const *suf[2] = {params->suffix1, params->suffix2};

@@ -677,3 +677,98 @@ uint32_t csh_crc32_combine_many(const uint32_t *crc, const uint32_t *len, int64_
 void csh_crc32_shift_table(uint32_t *out, uint32_t step) {
   for (uint32_t i = 0; i < 256; i++) out[i] = crc_x2nmodp((uint64_t)i * step, 3);
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * FASTA input (the reference reads whatever dnaio detects and asks input_file_format().has_qualities(),
+ * cutseq/run.py:437-441, 754-758).  The device parses four-line records, so FASTA text is re-shaped on its way in:
+ *     >name          ->  @name
+ *     ACGT                ACGTACGT        (sequence lines joined)
+ *     ACGT                +
+ *                         ~~~~~~~~        (a quality no cutoff trims: the QualityTrimmer step is a no-op without
+ *                                          qualities; the output side writes FASTA records, so it never shows)
+ * Reader rules as dnaio's FastaReader: lines are stripped of white space at both ends, empty lines and lines that start
+ * with '#' are skipped, a record starts at a line that starts with '>', anything else before the first record is an
+ * error.  Only WHOLE records are converted: `*consumed` stops at the start of the last record unless `final` is set
+ * (the caller carries the rest into the next call).  Returns the bytes written, -1 when `cap` is too small (3 * n + 16
+ * always suffices), -2 on a format error (*err_line = 1-based line of the call's text).
+ */
+static int fa_space(uint8_t c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+int64_t csh_fasta_to_fastq(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap, int final, int in_record,
+                           int64_t *consumed, int64_t *records, int64_t *err_line) {
+  int64_t o = 0, pos = 0, line = 0, recs = 0;
+  int64_t rec_src = -1, rec_dst = 0; /* the open record: where it starts in src / dst */
+  int64_t seq_len = 0;
+  int open = 0;
+  (void)in_record;
+  *consumed = 0;
+  *records = 0;
+  *err_line = 0;
+  while (pos < n) {
+    /* one line: [pos, eol) */
+    const uint8_t *nl = memchr(src + pos, '\n', (size_t)(n - pos));
+    int64_t eol = nl ? (int64_t)(nl - src) : n;
+    if (!nl && !final) break; /* an incomplete line: the caller brings the rest */
+    int64_t a = pos, b = eol;
+    while (a < b && fa_space(src[a])) ++a;
+    while (b > a && fa_space(src[b - 1])) --b;
+    ++line;
+    const int64_t line_start = pos;
+    pos = nl ? eol + 1 : n;
+    if (a == b) continue;
+    if (src[a] == '>') {
+      if (open) { /* the record in front is complete: its '+' and quality lines */
+        if (o + 4 + seq_len + 1 > cap) return -1;
+        dst[o++] = '\n';
+        dst[o++] = '+';
+        dst[o++] = '\n';
+        memset(dst + o, '~', (size_t)seq_len);
+        o += seq_len;
+        dst[o++] = '\n';
+        ++recs;
+        *consumed = line_start;
+        *records = recs;
+      }
+      open = 1;
+      rec_src = line_start;
+      rec_dst = o;
+      seq_len = 0;
+      if (o + (b - a) + 1 > cap) return -1;
+      dst[o++] = '@';
+      memcpy(dst + o, src + a + 1, (size_t)(b - a - 1));
+      o += b - a - 1;
+      dst[o++] = '\n';
+    } else if (src[a] == '#') {
+      continue;
+    } else if (open) {
+      if (o + (b - a) > cap) return -1;
+      memcpy(dst + o, src + a, (size_t)(b - a));
+      o += b - a;
+      seq_len += b - a;
+    } else {
+      *err_line = line;
+      return -2;
+    }
+  }
+  if (open) {
+    if (final) {
+      if (o + 4 + seq_len + 1 > cap) return -1;
+      dst[o++] = '\n';
+      dst[o++] = '+';
+      dst[o++] = '\n';
+      memset(dst + o, '~', (size_t)seq_len);
+      o += seq_len;
+      dst[o++] = '\n';
+      ++recs;
+      *consumed = n;
+      *records = recs;
+    } else {
+      o = rec_dst; /* the open record waits for its end */
+      *consumed = rec_src;
+    }
+  } else {
+    *consumed = final ? n : pos; /* blank lines / comments only */
+  }
+  *records = recs;
+  return o;
+}

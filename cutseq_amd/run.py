@@ -332,6 +332,11 @@ def run_pipeline(args, tp: TrimPlan, shares=None) -> dict:
                                         shares=shares)
     if shares is not None:
         raise ValueError("--ranks needs the text path (no demultiplexing, CUTSEQ_TEXT_PATH unset)")
+    from . import codec
+    for name in args.input_file:  # the host parser reads plain and gzip FASTQ files, nothing else
+        container, first, _ = codec.sniff_input(name) if name != "-" else ("stdin", b"", None)
+        if container not in ("plain", "gzip") or first in (b">", b"#"):
+            _fail(f"{name}: FASTA input, standard input and bzip2 / xz / zstandard files need the text path (CUTSEQ_TEXT_PATH unset).")
     chunk_reads = int(os.environ.get("CUTSEQ_CHUNK_READS", fastq.CHUNK_READS))
     paired = tp.paired
     in1 = args.input_file[0]

@@ -58,6 +58,9 @@ def _host():
         L.csh_count_newlines.argtypes = [C.c_void_p, C.c_int64]
         L.csh_after_kth_newline.restype = C.c_int64
         L.csh_after_kth_newline.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        L.csh_fasta_to_fastq.restype = C.c_int64
+        L.csh_fasta_to_fastq.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L._text_bound = True
     return L
 
@@ -89,7 +92,15 @@ class TextReader(threading.Thread):
         self.start_at, self.skip_lines, self.max_records = start, skip_lines, max_records
         self.blocks: "queue.Queue" = queue.Queue(maxsize=3)
         self._halt = False
-        self.gz = codec.is_gzip(path)
+        # What the file holds decides how it is read (dnaio / xopen go by content too, cutseq/run.py:434-441, 751-758):
+        # gzip and plain FASTQ files take the parallel paths; standard input ("-"), bzip2 / xz / zstandard files and
+        # FASTA text come through a sequential reader (codec.StreamSource), FASTA re-shaped into four-line records.
+        self.container, first, self._opener = codec.sniff_input(path)
+        self.fasta = first in (b">", b"#")  # (dnaio: a leading comment line means FASTA too)
+        self.sequential = path == "-" or self.container in ("bz2", "xz", "zst") or (self.fasta and self.container == "plain")
+        self.gz = self.container == "gzip" and not self.sequential
+        if (self.sequential or self.fasta) and (start or skip_lines or max_records is not None):
+            raise ValueError(f"{path}: only plain and gzip FASTQ files can be split between ranks")
         self.start()
 
     # -- plumbing ---------------------------------------------------------------------------------------
@@ -141,6 +152,14 @@ class TextReader(threading.Thread):
         if isinstance(text.base, fastq.mmap.mmap):
             fastq.ARENA.give(text)
 
+    @staticmethod
+    def _fasta_convert(data: bytes, out: np.ndarray, final: bool):
+        """-> (bytes written | -1 | -2, bytes of ``data`` consumed, line of a format error)"""
+        consumed, records, err_line = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        produced = _host().csh_fasta_to_fastq(data, len(data), out.ctypes.data, out.size, 1 if final else 0, 0,
+                                              C.byref(consumed), C.byref(records), C.byref(err_line))
+        return int(produced), int(consumed.value), int(err_line.value)
+
     def _read_plain(self, fd: int, pos: int, buf: np.ndarray, fill: int, want: int):
         """``want`` bytes of the file from ``pos`` on, several preads (and newline counts) at once in the pool."""
         L = _host()
@@ -185,10 +204,18 @@ class TextReader(threading.Thread):
         skip = self.skip_lines
         left = self.max_records  # records still to hand out (None: everything)
         copies: List = []  # inflated blocks on their way into `buf` (copied by the pool, awaited before `buf` is read)
-        if self.gz:
+        if self.gz and not self.fasta:
             src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give,
                                    post=lambda addr, nbytes: int(L.csh_count_newlines(addr, nbytes)))
             gen = src.blocks(self.start_at)
+        elif self.gz or self.sequential:
+            if self.gz:  # (FASTA in a gzip file: the members still inflate in the pool)
+                src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give)
+            else:
+                src = codec.StreamSource(self._opener(), fastq.ARENA.take, fastq.ARENA.give)
+            if self.fasta:
+                src = codec.FastaSource(src, self._fasta_convert, fastq.ARENA.take, fastq.ARENA.give, self.path)
+            gen = src.blocks(0)
         else:
             fd = os.open(self.path, os.O_RDONLY)
         try:
@@ -391,11 +418,24 @@ class StreamWriter:
 
     def __init__(self, path: str, level: int = 1, precompressed: bool = False):
         """``precompressed``: what arrives are finished gzip members (the device compressed them): written as they are."""
-        self.path, self.level, self.gz = path, level, path.endswith(".gz")
+        # xopen's rules (cutseq/run.py:437, 754: OutputFiles): the container goes by the name's extension, "-" is
+        # standard output.  gzip and plain files keep their parallel paths; bzip2 / xz / zstandard streams are
+        # compressed by this writer's own thread (stdlib codecs), standard output takes sequential writes.
+        self.path, self.level = path, level
+        self.container = codec.container_of_name(path) if path != "-" else "plain"
+        self.gz = self.container == "gzip"
         self.precompressed = precompressed and self.gz
-        self.fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
+        self.codec = codec.make_compressor(self.container, level) if self.container in ("bz2", "xz", "zst") else None
+        self.stdout = path == "-"
+        if self.stdout:
+            import sys
+            sys.stdout.flush()
+            self.fd = os.dup(1)
+        else:
+            self.fd = os.open(path, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o666)
         self.pos = 0
-        self.mappable = not self.gz  # (gzip members are small: plain pwrite, the pool has better things to do)
+        # (gzip members are small: plain pwrite, the pool has better things to do)
+        self.mappable = self.container == "plain" and not self.stdout
         self._can_allocate = True    # plain output: fallocate works on this file (system)
         self.q: "queue.Queue" = queue.Queue()
         self.err: Optional[BaseException] = None
@@ -417,8 +457,16 @@ class StreamWriter:
         """``data`` at the end of the file.  Writes to ONE file serialise on its inode lock whatever the number of
         threads, so big plain pieces do not go through write(2): the file is extended, the new range mapped, and the
         pool copies into the mapping -- page faults and copies of different pages run side by side."""
+        if self.codec is not None:
+            data = self.codec[0](data)
         mv = memoryview(data)
         n = len(mv)
+        if self.stdout:
+            at = 0
+            while at < n:
+                at += os.write(self.fd, mv[at:])
+            self.pos += n
+            return
         if n >= _MAP_MIN and self.mappable:
             try:
                 self._copy_mapped(mv, n)
@@ -493,6 +541,9 @@ class StreamWriter:
         try:
             if self.err is None and self.gz and self.pos == 0:
                 self._write_all(codec.gzip_member(b"", self.level))  # an empty stream is still a valid gzip file
+            if self.err is None and self.codec is not None:
+                tail, self.codec = self.codec[1](), None
+                self._write_all(tail)
         finally:
             os.close(self.fd)
         if self.err is not None:
@@ -511,9 +562,11 @@ class TextWorker(threading.Thread):
 
     SLOTS = 3
 
-    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int, compress: bool = False, bins: int = 0):
+    def __init__(self, tp, device: int, done: "queue.Queue", chunk_reads: int, compress: bool = False, bins: int = 0,
+                 fasta: bool = False):
         super().__init__(daemon=True, name=f"cutseq-gpu{device}")
         self.tp, self.device, self.done, self.chunk_reads, self.compress = tp, device, done, chunk_reads, compress
+        self.fasta = fasta  # the records leave as FASTA
         self.bins = bins  # demultiplexing: one route per barcode behind the three ordinary ones
         self.inbox: "queue.Queue" = queue.Queue(maxsize=self.SLOTS)
         self.engine = self.text = None
@@ -542,7 +595,7 @@ class TextWorker(threading.Thread):
         self.capacity = max(self.capacity, int(text_bytes * 1.25) + (1 << 20))
         self.text = textpath.TextEngine(self.engine, slots=self.SLOTS, max_text_bytes=self.capacity,
                                         max_records=self.chunk_reads, stride=self.stride, compress=self.compress,
-                                        bins=self.bins)
+                                        bins=self.bins, fasta=self.fasta)
         self.submitted = 0
 
     def _submit(self, inflight: deque, k: int, b1: TextBlock, b2: Optional[TextBlock]):
@@ -626,6 +679,39 @@ class TextWorker(threading.Thread):
                 self.done.put(self)
 
 
+_FASTA_EXT = (".fasta", ".fa", ".fna", ".csfasta", ".csfa")
+_FASTQ_EXT = (".fastq", ".fq")
+
+
+def format_of_name(name: str) -> Optional[str]:
+    """dnaio's rule for output files: the format goes by the extension in front of a compression suffix; None when
+    the name says nothing (the input's format then decides)."""
+    low = name.lower()
+    for ext in (".gz", ".bz2", ".xz", ".zst"):
+        if low.endswith(ext):
+            low = low[: -len(ext)]
+            break
+    if low.endswith(_FASTA_EXT):
+        return "fasta"
+    if low.endswith(_FASTQ_EXT):
+        return "fastq"
+    return None
+
+
+def output_format(names, has_qualities: bool) -> bool:
+    """-> True when the records leave as FASTA.  What OutputFiles(qualities=runner.input_file_format().has_qualities())
+    does in the reference (cutseq/run.py:437-441, 754-758): a name with a FASTA / FASTQ extension fixes the format,
+    any other name follows the input; FASTQ output of an input without qualities is an error (dnaio refuses it)."""
+    kinds = {format_of_name(n) or ("fastq" if has_qualities else "fasta") for n in names}
+    if "fastq" in kinds and not has_qualities:
+        raise fastq.FastqFormatError(
+            "Output format cannot be FASTQ since no quality values are available: the input is FASTA "
+            "(name the output files .fasta / .fa)")
+    if len(kinds) > 1:
+        raise ValueError("the output files name different formats (FASTA and FASTQ): one format per run")
+    return kinds == {"fasta"}
+
+
 def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
     """The CLI's run on the text path -> the run statistics ``report`` expects.  ``shares``: per input file the part
     of it this process takes (``ranks.py``)."""
@@ -650,6 +736,9 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         names_all = [n for group in [args.output_file if not n_bins else [], args.short_file, args.untrimmed_file] + bin_files
                      for n in group if n]
         compress = bool(names_all) and all(n.endswith(".gz") for n in names_all) and os.environ.get("CUTSEQ_GPU_DEFLATE", "1") != "0"
+        if r2 is not None and r1.fasta != r2.fasta:
+            raise fastq.FastqFormatError("the two input files are in different formats (one FASTA, one FASTQ)")
+        fasta_out = output_format(names_all, has_qualities=not r1.fasta)
 
         def mk(names):
             group = []
@@ -682,7 +771,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         from .run import _phase
         _phase("readers and writers open")
     done: "queue.Queue" = queue.Queue()
-    workers = [TextWorker(tp, dev, done, chunk_reads, compress, n_bins) for dev in devices]
+    workers = [TextWorker(tp, dev, done, chunk_reads, compress, n_bins, fasta_out) for dev in devices]
     if n_bins:
         totals["routes"] += [0] * n_bins
     budget = threading.Semaphore(2 * len(workers) * TextWorker.SLOTS + 2)  # batches between reader and disk

@@ -65,7 +65,7 @@ class TextEngine:
     """``slots`` batches in flight on one :class:`TrimEngine` (its plan, streams and statistics block)."""
 
     def __init__(self, engine: TrimEngine, slots: int = 3, max_text_bytes: int = 64 << 20, max_records: int = 1 << 18,
-                 stride: int = 152, compress: bool = False, bins: int = 0):
+                 stride: int = 152, compress: bool = False, bins: int = 0, fasta: bool = False):
         """``compress``: every route's output leaves the device as one gzip member (``res.route_bytes`` then counts
         compressed bytes): what ``.gz`` output files take as they are.  ``bins``: the plan demultiplexes (table form)
         into that many barcodes; the trimmed records of barcode b are route 3 + b (:meth:`routes`)."""
@@ -78,6 +78,7 @@ class TextEngine:
         p.untrimmed_filter = 1 if plan.untrimmed_filter else 0
         p.reverse_complement = 1 if plan.reverse_complement else 0
         p.compress = 1 if compress else 0
+        p.fasta_out = 1 if fasta else 0  # records leave as ">id\nsequence\n" (no qualities to write)
         self.compress = bool(compress)
         p.n_bins = int(bins)
         self.n_routes = 3 + int(bins)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 5
+#define CS_ABI_VERSION 6
 #define CS_MAX_ADAPTER 128 /* longest adapter sequence an op can carry          */
 #define CS_MAX_OPS 24      /* longest per-mate op chain                           */
 #define CS_MAX_STRIDE 1536 /* longest row the LDS tile can stage (64 rows/block) */
@@ -302,7 +302,10 @@ typedef struct cs_text_params {
   uint32_t n_bins;            /* plans with a CS_OP_DEMUX op (table form): the number of barcodes.  The trimmed
                                  records of barcode b then form route 3 + b (route 0 stays empty): 3 + n_bins streams
                                  per mate, back to back in route order; sizes through cs_text_routes.  0: no bins */
-  uint32_t _reserved;
+  uint8_t fasta_out;          /* records leave as FASTA (">id\nsequence\n"): the input had no qualities -- what
+                                 runner.input_file_format().has_qualities() tells OutputFiles, cutseq/run.py:437-441,
+                                 754-758 -- or the output files are named .fasta / .fa                              */
+  uint8_t _reserved[3];
 } cs_text_params;
 
 typedef struct cs_text_result {

@@ -112,6 +112,71 @@ def test_cli_zero_length_final_record(tmp_path, gz):
         assert open(out, "rb").read() == want, k
 
 
+def _fasta_expected(rec, scheme, st):
+    """The FASTA counterpart of `expected`: the oracle sees the reads with a quality no cutoff trims (the
+    QualityTrimmer step does nothing without qualities), the records leave as '>id\\nsequence\\n'."""
+    batch = util.batch_from_records([(n, s, b"~" * len(s)) for n, s, _ in rec])
+    out = util.pyref_run(scheme, st, batch, [r[0] for r in rec])
+    streams = {}
+    for route, name in enumerate(("trimmed", "short", "untrimmed")):
+        recs = [x[1] for x in out if x[0] == route]
+        streams[name] = b"".join(b">" + r.split(b"\n")[0][1:] + b"\n" + r.split(b"\n")[1] + b"\n" for r in recs)
+    return streams
+
+
+def test_cli_fasta_and_the_other_containers(tmp_path):
+    """What dnaio / xopen give the reference for free (cutseq/run.py:434-441, 751-758): FASTA input (here with wrapped
+    sequence lines) -> FASTA output, quality trimming a no-op; FASTQ input to a file named .fasta; bzip2 / xz files on
+    both sides; FASTQ output names for a FASTA input are refused as dnaio refuses them."""
+    import bz2
+    import lzma
+    rec = util.read_fastq_gz(R1, limit=400)
+    st = planmod.CutadaptConfig()
+    scheme = BUILDIN_ADAPTERS["TAKARAV3"]
+    want = _fasta_expected(rec, scheme, st)
+    fasta = b"".join(b">" + n + b"\n" + b"\n".join(s[i:i + 70] for i in range(0, len(s), 70)) + b"\n" for n, s, _ in rec)
+    (tmp_path / "in.fa").write_bytes(fasta)
+    (tmp_path / "in.fasta.bz2").write_bytes(bz2.compress(fasta))
+    for k, (src, dst, undo) in enumerate((("in.fa", "o.fasta", bytes), ("in.fasta.bz2", "o.fa.xz", lzma.decompress),
+                                          ("in.fa", "o.fa.gz", gzip.decompress))):
+        out, short = str(tmp_path / f"{k}_{dst}"), str(tmp_path / f"{k}_s_{dst}")
+        cli.main([str(tmp_path / src), "-A", "TAKARAV3", "-o", out, "-s", short])
+        assert undo(open(out, "rb").read()) == want["trimmed"], (src, dst)
+        assert undo(open(short, "rb").read()) == want["short"], (src, dst)
+    from cutseq_amd import fastq
+    with pytest.raises(fastq.FastqFormatError, match="no quality values"):  # (an exception, as from dnaio in the reference)
+        cli.main([str(tmp_path / "in.fa"), "-A", "TAKARAV3", "-O", str(tmp_path / "pre")])  # -> *_trimmed_R1.fastq.gz
+    # FASTQ input, FASTA-named output: sequences of the ordinary run (quality trimming included), no quality lines
+    fq = expected(scheme, {}, False)
+    out, short = str(tmp_path / "q.fa.bz2"), str(tmp_path / "q_s.fa.bz2")
+    cli.main([R1, "-A", "TAKARAV3", "-o", out, "-s", short])
+    lines = fq["trimmed"][0].split(b"\n")
+    as_fasta = b"".join(b">" + lines[i][1:] + b"\n" + lines[i + 1] + b"\n" for i in range(0, len(lines) - 1, 4))
+    assert bz2.decompress(open(out, "rb").read()) == as_fasta
+    # xz FASTQ in, bzip2 FASTQ out
+    (tmp_path / "in.fq.xz").write_bytes(lzma.compress(gunzip(R1), preset=0))
+    out, short = str(tmp_path / "x.fq.bz2"), str(tmp_path / "x_s.fq.bz2")
+    cli.main([str(tmp_path / "in.fq.xz"), "-A", "TAKARAV3", "-o", out, "-s", short])
+    assert bz2.decompress(open(out, "rb").read()) == fq["trimmed"][0]
+    assert bz2.decompress(open(short, "rb").read()) == fq["short"][0]
+
+
+def test_cli_standard_input_and_output(tmp_path):
+    """'-' as input / output file name (xopen): FASTQ text and a gzip stream on standard input, the trimmed records on
+    standard output, in a child process."""
+    import subprocess
+    import sys
+    want = expected(BUILDIN_ADAPTERS["TAKARAV3"], {}, False)
+    root = str(util.GOLDEN.parents[1])
+    for blob in (gunzip(R1), open(R1, "rb").read()):
+        short = str(tmp_path / "s.fq")
+        r = subprocess.run([sys.executable, "-m", "cutseq_amd.run", "-", "-A", "TAKARAV3", "-o", "-", "-s", short],
+                           input=blob, capture_output=True, cwd=root, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert r.stdout == want["trimmed"][0]
+        assert open(short, "rb").read() == want["short"][0]
+
+
 # ---------------------------------------------------------------- the runner beyond one chunk
 
 

@@ -751,6 +751,76 @@ def test_text_reader_zero_length_final_record(tmp_path, unpinned, gz, tail, bloc
         _drain(textio.TextReader(str(path), 7000))
 
 
+def test_fasta_input_is_reshaped_into_four_line_records(tmp_path, unpinned):
+    """FASTA input (the reference takes whatever dnaio detects, cutseq/run.py:437-441, 754-758): names as they are,
+    sequence lines joined, white space at line ends stripped, blank lines and '#' comments skipped, a quality line no
+    cutoff trims -- in blocks of whole records, whatever the container; anything else in front of the first '>' is an
+    error with its line number."""
+    import bz2
+    import lzma
+    from cutseq_amd import textio
+    recs = [(b"r%d some comment" % i, b"ACGTNacgt" * (1 + i % 30)) for i in range(30_001)]
+    want = b"".join(b"@" + n + b"\n" + s + b"\n+\n" + b"~" * len(s) + b"\n" for n, s in recs)
+    wrapped = b"# a comment line\n\n" + b"".join(
+        b">" + n + b"  \r\n" + b"\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + b"\n\n" for n, s in recs)
+    for name, blob in (("in.fa", wrapped), ("in.fa.gz", gzip.compress(wrapped, 1)), ("in.fa.bz2", bz2.compress(wrapped, 1)),
+                       ("in.fa.xz", lzma.compress(wrapped, preset=0)), ("noext", wrapped[:-2])):
+        path = tmp_path / name
+        path.write_bytes(blob)
+        reader = textio.TextReader(str(path), 7000)
+        assert reader.fasta
+        got, sizes = _drain(reader)
+        assert sizes == [7000, 7000, 7000, 7000, 2001], name
+        assert got == want[:-1], name
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b"# comment\nACGT\n>x\nAC\n")
+    with pytest.raises(ValueError, match="line 2"):
+        _drain(textio.TextReader(str(bad), 7000))
+
+
+def test_fastq_through_the_sequential_containers(tmp_path, unpinned):
+    """bzip2 / xz FASTQ files (xopen opens them for the reference): same blocks as the plain file."""
+    import bz2
+    import lzma
+    from cutseq_amd import textio
+    body = b"".join(b"@r%d x\n%s\n+\n%s\n" % (i, b"ACGT" * (5 + i % 40), b"IIII" * (5 + i % 40)) for i in range(25_001))
+    for name, blob in (("in.fq.bz2", bz2.compress(body, 1)), ("in.fq.xz", lzma.compress(body, preset=0))):
+        path = tmp_path / name
+        path.write_bytes(blob)
+        reader = textio.TextReader(str(path), 7000)
+        assert not reader.fasta and reader.sequential
+        got, sizes = _drain(reader)
+        assert sizes == [7000, 7000, 7000, 4001] and got == body[:-1]
+
+
+def test_output_format_rules():
+    """dnaio's rules for output files (OutputFiles(qualities=has_qualities()), cutseq/run.py:437-441, 754-758)."""
+    from cutseq_amd import textio
+    assert textio.output_format(["a.fastq.gz", "b.fq"], True) is False
+    assert textio.output_format(["a.fasta.gz", "b.fa"], True) is True      # FASTQ in, FASTA out: the name decides
+    assert textio.output_format(["a.txt"], False) is True                   # no extension to go by: follows the input
+    assert textio.output_format(["a.txt"], True) is False
+    with pytest.raises(fastq.FastqFormatError, match="no quality values"):
+        textio.output_format(["a_trimmed_R1.fastq.gz"], False)
+    with pytest.raises(ValueError):
+        textio.output_format(["a.fasta", "b.fastq"], True)
+
+
+def test_stream_writer_sequential_containers(tmp_path, unpinned):
+    import bz2
+    import lzma
+    from cutseq_amd import textio
+    parts = [bytes([65 + i % 20]) * n for i, n in enumerate((10, 3_000_000, 0, 9_000_000, 77))]
+    for name, undo in (("o.fq.bz2", bz2.decompress), ("o.fq.xz", lzma.decompress)):
+        w = textio.StreamWriter(str(tmp_path / name))
+        for p in parts:
+            buf = fastq.PINNED.take(max(len(p), 1))
+            buf[:len(p)] = np.frombuffer(p, dtype=np.uint8)
+            w.put(memoryview(buf)[:len(p)], textio._Shared([buf], 1, lambda: None))
+        w.close()
+        assert undo((tmp_path / name).read_bytes()) == b"".join(parts)
+
+
 def test_stream_writer_orders_pieces_and_releases_buffers(tmp_path, unpinned):
     from cutseq_amd import textio
     rng = np.random.default_rng(1)
