@@ -5,11 +5,19 @@ processes behind one reader.  Here the per-read work is on the GPUs and what has
 pushing on the host (read / inflate, upload, download, deflate / write), so every rank gets its own reader, its own
 thread pool, its own GPU and its own output part:
 
-  parent   no HIP call.  Splits the input at RECORD indices (rank r takes records [R r / N, R (r + 1) / N) of both
-           mates): one pass that counts newlines -- plain text: parallel ``pread`` + count, exact byte offsets;
-           gzip (multi-member / BGZF): members inflate in the pool, a rank starts at the member that holds its first
-           line and skips the lines in front of it.  Spawns the children, concatenates their output parts in rank
-           order (gzip members / plain text: the concatenation IS the file), merges the statistics, prints the report.
+  parent   no HIP call.  Splits the input so that rank r takes the same records of both mates:
+             * multi-member gzip files whose members hold the same records in both mates (what this CLI, and anything
+               else that writes R1 and R2 in lockstep, produces): by MEMBER INDEX, from a scan for member starts --
+               nothing is inflated twice.  The assumption is checked, not trusted: the first record ids at every split
+               point in the parent, every pair's ids and the record counts of the two mates in the ranks (the checks
+               every run makes); a run that fails them is started again with the exact split below.
+             * everything else: at RECORD indices from one counting pass -- plain text: parallel ``pread`` + newline
+               count, exact byte offsets; gzip: the members inflate in the pool (a second time in the ranks: the price
+               of members that do not line up), a rank starts at the member that holds its first line and skips the
+               lines in front of it.
+           Spawns the children with their share of the host threads, puts their output parts behind rank 0's files
+           (pre-sized, parallel in-kernel copies: gzip members / plain text -- the concatenation IS the file), merges
+           the statistics, prints the report.
   child    ``python -m cutseq_amd.run ... --rank-spec FILE``: the ordinary text path on its share, on its GPU.
 
 Output is byte-identical (decompressed) to the one-process run; no data crosses between ranks.
@@ -96,6 +104,97 @@ def _lines_gzip(path: str):
     return offs, counts, last
 
 
+def gzip_members(path: str) -> Optional[List[int]]:
+    """Start offsets of the members of a gzip file WITHOUT inflating it: every ``1f 8b 08`` with clean flag bits is a
+    candidate (csh_find_gzip_magic, a memchr walk), a candidate counts when the first kilobytes behind it inflate
+    without an error -- the magic turns up in compressed data by chance a few times per gigabyte, and such a place is
+    not the start of a deflate stream.  None: the file is not a gzip file / has one member only."""
+    import mmap
+    import zlib
+    size = os.path.getsize(path)
+    if size < 18:
+        return None
+    with open(path, "rb") as fh:
+        buf = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+    try:
+        if buf[:2] != b"\x1f\x8b":
+            return None
+        if codec._bgzf_block_size(buf, 0):
+            return None  # BGZF: 64 KB blocks cut anywhere in the text, and the reader walks them in spans of its own
+        H = codec._pinflate()
+        base = codec._view_address(memoryview(buf)) if H is not None else 0
+        out, pos = [0], 1
+        while pos < size - 18:
+            p = H.csh_find_gzip_magic(base, pos, size - 2) if H is not None else buf.find(b"\x1f\x8b\x08", pos)
+            if p < 0:
+                break
+            pos = p + 1
+            if (buf[p + 3] & 0xE0) != 0:
+                continue
+            try:
+                head = zlib.decompressobj(31).decompress(buf[p:min(size, p + 65536)], 4096)
+            except zlib.error:
+                continue
+            if head:
+                out.append(p)
+        return out if len(out) > 1 else None
+    finally:
+        try:
+            buf.close()
+        except BufferError:
+            pass
+
+
+def _first_id(path: str, offset: int) -> Optional[bytes]:
+    """The id of the record a member starts with (up to the first blank, one trailing 1 / 2 / 3 dropped: dnaio's
+    record_names_match); None when the member does not start with a record."""
+    import zlib
+    with open(path, "rb") as fh:
+        fh.seek(offset)
+        raw = fh.read(1 << 16)
+    try:
+        text = zlib.decompressobj(31).decompress(raw, 1 << 14)
+    except zlib.error:
+        return None
+    line = text.split(b"\n", 1)[0]
+    if not line.startswith(b"@"):
+        return None
+    name = line[1:].split(b" ", 1)[0].split(b"\t", 1)[0]
+    return name[:-1] if name[-1:] in (b"1", b"2", b"3") else name
+
+
+def split_by_members(paths: List[str], world: int):
+    """-> (shares[rank][file] = dict(start, stop), None) or (None, reason): ranks take member index ranges -- valid when
+    member k holds the same records in every file, which is checked at every split point (and record for record in
+    the ranks)."""
+    index = []
+    for path in paths:
+        if not codec.is_gzip(path):
+            return None, f"{path} is not a gzip file"
+        members = gzip_members(path)
+        if members is None:
+            return None, f"{path} is one gzip member"
+        index.append(members)
+    n = len(index[0])
+    if any(len(m) != n for m in index):
+        return None, "the input files have different numbers of gzip members"
+    if n < world:
+        return None, "fewer gzip members than ranks"
+    cuts = [n * r // world for r in range(world + 1)]
+    for k in cuts[1:-1]:
+        ids = [_first_id(path, members[k]) for path, members in zip(paths, index)]
+        if any(i is None for i in ids) or len(set(ids)) != 1:
+            return None, "the members of the input files do not hold the same records"
+    shares = []
+    for r in range(world):
+        row = []
+        for path, members in zip(paths, index):
+            stop = members[cuts[r + 1]] if cuts[r + 1] < n else None
+            row.append({"start": int(members[cuts[r]]), "stop": stop})
+        shares.append(row)
+    return shares, None
+
+
 def split_inputs(paths: List[str], world: int):
     """-> (shares[rank][file] = dict(start, skip_lines, max_records), records) or (None, reason)."""
     tables, totals = [], []
@@ -140,27 +239,52 @@ def split_inputs(paths: List[str], world: int):
     return shares, records
 
 
-def _concatenate(parts: List[str], final: str) -> None:
-    with open(final, "wb") as dst:
-        for part in parts:
-            with open(part, "rb") as src:
-                size = os.fstat(src.fileno()).st_size
-                at = 0
-                while at < size:
+def _append_parts(final: str, parts: List[str]) -> None:
+    """``final`` (rank 0's file) + the other ranks' parts, in rank order: the file is extended to its final size once and
+    every part is copied to its place with in-kernel copies, all parts at once (gzip members / plain text: the
+    concatenation IS the file)."""
+    sizes = [os.path.getsize(p) for p in parts]
+    if not parts:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    fd = os.open(final, os.O_RDWR)
+    try:
+        base = os.fstat(fd).st_size
+        os.ftruncate(fd, base + sum(sizes))
+        offsets = [base + sum(sizes[:i]) for i in range(len(parts))]
+
+        def copy(job):
+            part, at, size = job
+            src = os.open(part, os.O_RDONLY)
+            try:
+                done = 0
+                while done < size:
                     try:
-                        sent = os.sendfile(dst.fileno(), src.fileno(), at, size - at)
-                    except OSError:
-                        sent = 0
-                    if sent <= 0:  # no in-kernel copy between these files: ordinary copy of the rest
-                        src.seek(at)
-                        while True:
-                            block = src.read(8 << 20)
+                        n = os.copy_file_range(src, fd, size - done, done, at + done)
+                    except (OSError, AttributeError):
+                        n = 0
+                    if n <= 0:  # no in-kernel copy between these files: an ordinary one for the rest
+                        while done < size:
+                            block = os.pread(src, min(8 << 20, size - done), done)
                             if not block:
-                                break
-                            dst.write(block)
+                                raise OSError(f"{part}: shorter than its size")
+                            os.pwrite(fd, block, at + done)
+                            done += len(block)
                         break
-                    at += sent
+                    done += n
+            finally:
+                os.close(src)
             os.unlink(part)
+
+        with ThreadPoolExecutor(max(1, min(8, len(parts)))) as pool:
+            list(pool.map(copy, zip(parts, offsets, sizes)))
+    finally:
+        os.close(fd)
+
+
+def _host_threads(args) -> int:
+    return int(args.threads) if getattr(args, "threads", None) else fastq.pool_size()
 
 
 def run_parent(argv: List[str], args, tp) -> Optional[dict]:
@@ -168,11 +292,39 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
     to one process."""
     world = int(args.ranks)
     paths = list(args.input_file)
+    names_all = [n for names in (args.output_file, args.short_file, args.untrimmed_file) for n in names if n]
+    if "-" in paths or "-" in names_all:
+        logging.warning(f"--ranks {world} ignored: standard input / output cannot be shared between ranks.")
+        return None
+    for path in paths:
+        container, first, _ = codec.sniff_input(path)
+        if container not in ("plain", "gzip") or first in (b">", b"#"):
+            logging.warning(f"--ranks {world} ignored: {path} is not a plain or gzip FASTQ file.")
+            return None
     t0 = time.perf_counter()
+    if getattr(args, "threads", None):
+        try:
+            fastq.set_threads(args.threads)  # (the counting pass below honours -t too)
+        except RuntimeError:
+            pass
+    shares, why = split_by_members(paths, world)
+    if shares is not None:
+        try:
+            return _run_ranks(argv, args, world, shares, t0, "gzip members (nothing inflated twice)")
+        except RankFailure as exc:
+            logging.warning(f"--ranks {world}: the split by gzip members did not hold ({exc}); once more with the exact split.")
     shares, info = split_inputs(paths, world)
     if shares is None:
         logging.warning(f"--ranks {world} ignored: {info}.")
         return None
+    return _run_ranks(argv, args, world, shares, t0, f"record indices from a counting pass ({why})")
+
+
+class RankFailure(RuntimeError):
+    pass
+
+
+def _run_ranks(argv: List[str], args, world: int, shares, t0: float, how: str) -> dict:
     want = os.environ.get("CUTSEQ_DEVICES")
     devices = [int(x) for x in want.split(",")] if want else list(range(world))
     groups = {"output_file": args.output_file, "short_file": args.short_file, "untrimmed_file": args.untrimmed_file}
@@ -182,14 +334,21 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
         groups["output_file"] = [None] * len(args.output_file)  # (nothing is written under the common trimmed names)
     work = tempfile.mkdtemp(prefix="cutseq_ranks_")
     children, specs = [], []
-    child_argv = _strip_option(argv, "--ranks")
+    # every rank gets its share of the host threads (N pools of all cores each would oversubscribe the host N times)
+    per_rank = max(1, _host_threads(args) // world)
+    child_argv = _strip_option(_strip_option(_strip_option(argv, "--ranks"), "--threads"), "-t") + ["-t", str(per_rank)]
+
+    def part_name(name, r):  # rank 0 writes the final files themselves; a part keeps the container's ending
+        if not name or r == 0:
+            return name
+        ending = next((e for e in (".gz", ".bz2", ".xz", ".zst") if name.endswith(e)), "")
+        return f"{name}.rank{r}.part{ending}"
+
     try:
         for r in range(world):
             spec = {
                 "rank": r, "world": world, "inputs": shares[r],
-                # (a part keeps the ".gz" ending: the writers pick their codec by the name)
-                "outputs": {k: [(f"{name}.rank{r}.part{'.gz' if name.endswith('.gz') else ''}" if name else None) for name in names]
-                            for k, names in groups.items()},
+                "outputs": {k: [part_name(name, r) for name in names] for k, names in groups.items()},
                 "totals_file": os.path.join(work, f"totals{r}.json"),
             }
             path = os.path.join(work, f"spec{r}.json")
@@ -198,13 +357,21 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
             specs.append(spec)
             env = dict(os.environ, CUTSEQ_DEVICES=str(devices[r % len(devices)]), CUTSEQ_PROGRESS="0")  # (one Done line: the parent's)
             children.append(subprocess.Popen([sys.executable, "-m", "cutseq_amd.run"] + child_argv + ["--rank-spec", path], env=env))
-        codes = [c.wait() for c in children]
-        if any(codes):
-            raise RuntimeError(f"rank {next(i for i, c in enumerate(codes) if c)} failed (exit code {max(codes)})")
+        left = list(range(world))
+        while left:  # a rank that dies is noticed at once, whatever its number, and takes the others with it
+            for r in list(left):
+                code = children[r].poll()
+                if code is None:
+                    continue
+                left.remove(r)
+                if code != 0:
+                    raise RankFailure(f"rank {r} failed (exit code {code})")
+            if left:
+                time.sleep(0.01)
         for key, names in groups.items():
             for i, name in enumerate(names):
                 if name:
-                    _concatenate([s["outputs"][key][i] for s in specs], name)
+                    _append_parts(name, [s["outputs"][key][i] for s in specs[1:]])
         totals = report.new_totals()
         stats, devs = [], []
         for s in specs:
@@ -214,7 +381,8 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
             stats += part["stats"]
             devs += part["devices"]
         bin_names = list(args.demux[0]) if getattr(args, "demux", None) else None
-        totals.update(stats=stats, devices=devs, bin_names=bin_names, seconds=time.perf_counter() - t0, ranks=world)
+        totals.update(stats=stats, devices=devs, bin_names=bin_names, seconds=time.perf_counter() - t0, ranks=world,
+                      ranks_split=how, threads_per_rank=per_rank)
         progress = report.Progress()
         progress.t0 -= totals["seconds"]
         progress.update(totals["in_pairs"])
@@ -224,6 +392,11 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
         for c in children:
             if c.poll() is None:
                 c.kill()
+        for c in children:
+            try:
+                c.wait(timeout=30)
+            except Exception:  # noqa: BLE001
+                pass
         for s in specs:
             for names in s["outputs"].values():
                 for name in names:

@@ -157,6 +157,8 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
         "engine": {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
                    "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
                    "per_device": totals["stats"],
+                   **({"ranks": totals["ranks"], "ranks_split": totals.get("ranks_split"),
+                       "threads_per_rank": totals.get("threads_per_rank")} if totals.get("ranks") else {}),
                    **({"demultiplexed": dict(zip(totals.get("bin_names") or [], totals["routes"][3:]))}
                       if tp.demux is not None else {})},
         "input": {"path1": input1, "path2": input2, "paired": True if input2 else False},

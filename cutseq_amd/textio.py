@@ -83,13 +83,15 @@ class TextReader(threading.Thread):
     """One input file -> :class:`TextBlock` objects of exactly ``chunk_reads`` records (the last one may be shorter),
     then ``None``.  Exceptions travel through the queue."""
 
-    def __init__(self, path: str, chunk_reads: int, start: int = 0, skip_lines: int = 0, max_records: Optional[int] = None):
-        """``start`` / ``skip_lines`` / ``max_records``: one rank's share of the file in the multi-process form
+    def __init__(self, path: str, chunk_reads: int, start: int = 0, skip_lines: int = 0, max_records: Optional[int] = None,
+                 stop: Optional[int] = None):
+        """``start`` / ``skip_lines`` / ``max_records`` / ``stop``: one rank's share of the file in the multi-process form
         (``ranks.py``): begin at byte ``start`` (plain text) or at the gzip member that starts there, drop
-        ``skip_lines`` lines, stop behind ``max_records`` records (None = to the end of the file)."""
+        ``skip_lines`` lines, stop behind ``max_records`` records (None = to the end of the file) or in front of the
+        gzip member that starts at compressed offset ``stop``."""
         super().__init__(daemon=True, name=f"cutseq-read-{os.path.basename(path)}")
         self.path, self.chunk_reads = path, chunk_reads
-        self.start_at, self.skip_lines, self.max_records = start, skip_lines, max_records
+        self.start_at, self.skip_lines, self.max_records, self.stop_at = start, skip_lines, max_records, stop
         self.blocks: "queue.Queue" = queue.Queue(maxsize=3)
         self._halt = False
         # What the file holds decides how it is read (dnaio / xopen go by content too, cutseq/run.py:434-441, 751-758):
@@ -99,7 +101,8 @@ class TextReader(threading.Thread):
         self.fasta = first in (b">", b"#")  # (dnaio: a leading comment line means FASTA too)
         self.sequential = path == "-" or self.container in ("bz2", "xz", "zst") or (self.fasta and self.container == "plain")
         self.gz = self.container == "gzip" and not self.sequential
-        if (self.sequential or self.fasta) and (start or skip_lines or max_records is not None):
+        if (self.sequential or self.fasta or (stop is not None and not self.gz)) and (
+                start or skip_lines or max_records is not None or stop is not None):
             raise ValueError(f"{path}: only plain and gzip FASTQ files can be split between ranks")
         self.start()
 
@@ -151,6 +154,19 @@ class TextReader(threading.Thread):
         C.memmove(dst, text.ctypes.data, nbytes)
         if isinstance(text.base, fastq.mmap.mmap):
             fastq.ARENA.give(text)
+
+    @staticmethod
+    def _members_until(src, start: int, stop: int):
+        """The blocks of the members in [start, stop) (compressed offsets; the share of a rank that splits by members)."""
+        gen = src.indexed_blocks(start)
+        try:
+            for off, arr, nbytes in gen:
+                if off >= stop:
+                    src.give(arr)
+                    return
+                yield arr, nbytes
+        finally:
+            gen.close()
 
     @staticmethod
     def _fasta_convert(data: bytes, out: np.ndarray, final: bool):
@@ -207,7 +223,7 @@ class TextReader(threading.Thread):
         if self.gz and not self.fasta:
             src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give,
                                    post=lambda addr, nbytes: int(L.csh_count_newlines(addr, nbytes)))
-            gen = src.blocks(self.start_at)
+            gen = src.blocks(self.start_at) if self.stop_at is None else self._members_until(src, self.start_at, self.stop_at)
         elif self.gz or self.sequential:
             if self.gz:  # (FASTA in a gzip file: the members still inflate in the pool)
                 src = codec.GzipSource(self.path, fastq._pool(), fastq.ARENA.take, fastq.ARENA.give)

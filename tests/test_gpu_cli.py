@@ -369,18 +369,22 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(launcher):
     assert "cpu_baseline" not in rep  # rank 0 at N = 1 only
 
 
-def test_cli_two_ranks_equal_one_process(tmp_path, monkeypatch):
-    """--ranks 2 (two processes, both on GPU 0 here): the input split at record indices -- one mate plain text, the
-    other multi-member gzip --, every rank with its own reader, engine and output part; the concatenated output and
-    the report equal the one-process run (counterpart of make_runner(cores=N), cutseq/run.py:436, 753)."""
+@pytest.mark.parametrize("layout", ["plain+gz", "gz-members-in-lockstep", "gz-members-out-of-step"])
+def test_cli_two_ranks_equal_one_process(tmp_path, monkeypatch, layout):
+    """--ranks 2 (two processes, both on GPU 0 here), every rank with its own reader, engine and output part; the
+    concatenated output and the report equal the one-process run (counterpart of make_runner(cores=N),
+    cutseq/run.py:436, 753).  Layouts: one mate plain text, the other multi-member gzip (split at record indices from
+    a counting pass); both mates gzip with the same records per member (split by member index, nothing inflated
+    twice); gzip members that do not line up (the parent's id check at the split point sends it to the exact split)."""
     from cutseq_amd import synth
     n = 50_000
     batch = synth.generate_pairs(n, 150, seed=31, poly_fraction=0.05)
     names1 = [s.encode() for s in synth.headers(n, 1)]
     names2 = [s.encode() for s in synth.headers(n, 2)]
-    in1, in2 = str(tmp_path / "in_R1.fastq"), str(tmp_path / "in_R2.fastq.gz")
-    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1)
-    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=6_000)
+    in1 = str(tmp_path / ("in_R1.fastq" if layout == "plain+gz" else "in_R1.fastq.gz"))
+    in2 = str(tmp_path / "in_R2.fastq.gz")
+    util.write_fastq(in1, names1, batch.seq1, batch.qual1, batch.len1, gz_members=6_000)
+    util.write_fastq(in2, names2, batch.seq2, batch.qual2, batch.len2, gz_members=6_250 if layout.endswith("out-of-step") else 6_000)
     monkeypatch.setenv("CUTSEQ_CHUNK_READS", "8000")
     one, two = str(tmp_path / "one"), str(tmp_path / "two")
     cli.main(["-A", "TAKARAV3", "--trim-polyA", "-O", one, "--json-file", str(tmp_path / "one.json"), in1, in2])
@@ -393,3 +397,5 @@ def test_cli_two_ranks_equal_one_process(tmp_path, monkeypatch):
     assert a["read_counts"] == b["read_counts"] and a["basepair_counts"] == b["basepair_counts"]
     assert b["read_counts"]["input"] == n and len(b["engine"]["per_device"]) == 2
     assert not list(tmp_path.glob("*.part*"))
+    assert b["engine"]["ranks"] == 2 and b["engine"]["threads_per_rank"] >= 1
+    assert b["engine"]["ranks_split"].startswith("gzip members" if layout == "gz-members-in-lockstep" else "record indices")
