@@ -271,7 +271,7 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
   if (mode == csdev::MODE_RESOLVE) {
     g.col_dwords = eng->col_dwords;
     if (eng->knob_col_bytes / 4 > g.col_dwords) g.col_dwords = eng->knob_col_bytes / 4;
-    words += g.col_dwords + 64 * (csdev::kWaveItemDwords + csdev::kParkDwords);
+    words += g.col_dwords + 64 * csdev::kWaveItemDwords;
   }
   g.lds_bytes = words * 4;
   if (g.lds_bytes > kLdsBudget) return fail(CS_ERR_ARG, "stride %u does not fit the LDS tile", stride);
