@@ -505,6 +505,36 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
         for (int idx = 0; idx < mm && idx < 32; ++idx)
           d.fnib[idx >> 3] |= (uint32_t)((d.op.seq[d.op.reversed ? mm - 1 - idx : idx] >> 3) & 7u) << (4 * (idx & 7));
     }
+  // runs of consecutive CUT ops: walked in one turn of the op loop from the run's first op (DevOp::cut_run / cut_pack)
+  for (int m = 0; m < 2; ++m)
+    for (int i = 0; i < cnt[m]; ++i) {
+      csdev::DevOp &d = p->host.ops[m][i];
+      if (d.op.kind != CS_OP_CUT) continue;
+      auto pack = [](const cs_op &o) {
+        return (uint32_t)(uint16_t)o.cut_len | ((uint32_t)(o.conditional ? 1u : 0u) << 16) | ((uint32_t)(o.capture & 3u) << 17) |
+               ((uint32_t)(o.force_min_len > 0x1fff ? 0x1fffu : o.force_min_len) << 19);
+      };
+      d.cut_run = 1;
+      d.cut_pack[0] = pack(d.op);
+    }
+  {
+    const char *env = getenv("CUTSEQ_CUT_RUNS");
+    if (!(env && atoi(env) == 0))
+      for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < cnt[m];) {
+          if (p->host.ops[m][i].op.kind != CS_OP_CUT) {
+            ++i;
+            continue;
+          }
+          int j = i;
+          while (j < cnt[m] && j - i < csdev::kCutRun && p->host.ops[m][j].op.kind == CS_OP_CUT) {
+            p->host.ops[m][i].cut_pack[j - i] = p->host.ops[m][j].cut_pack[0];
+            ++j;
+          }
+          p->host.ops[m][i].cut_run = (uint32_t)(j - i);
+          i = j;
+        }
+  }
   // The pair that opens the reference's chains (cutseq/run.py:332-355, 544-590): an existence-only 5' op at the head
   // of the chain with a forward, free-ended Myers-32 op right behind it -> one merged forward walk in the scan kernel
   // (trim_kernel.hip.inc, myers_pair).  CUTSEQ_PAIR=0 keeps the two scans apart.
