@@ -1278,6 +1278,7 @@ struct cs_text {
   uint32_t seg_blocks = 0, fmt_blocks = 0;
   bool needs_cap2 = false;
   bool compress = false;      // the output streams leave the device as gzip members
+  bool literal_only = false;  // ... from literal-only blocks (CUTSEQ_GPU_LZ=0: no run / record-name matches)
   uint32_t max_chunks = 0;
   uint32_t n_routes = 3;      // 3 + cs_text_params.n_bins
   hipStream_t h2d = nullptr, d2h = nullptr;
@@ -1357,6 +1358,10 @@ int cs_text_create(cs_engine *eng, const cs_text_params *params, uint32_t n_slot
   // a second capture exists only in single-end chains (cs_cap2)
   t->needs_cap2 = !eng->paired && params->has_umi;
   t->compress = params->compress != 0;
+  {
+    const char *env = getenv("CUTSEQ_GPU_LZ");
+    t->literal_only = env && atoi(env) == 0;
+  }
   if (params->n_bins) {
     if (params->n_bins > 255u || eng->demux_mate < 0) {
       delete t;
@@ -1624,6 +1629,9 @@ int cs_text_submit(cs_text *t, uint32_t slot, const void *text1, uint64_t bytes1
         da.info = s.d_chunk[m];
         da.max_chunks = t->max_chunks;
         da.gate = &s.d_meta->err;
+        da.marker = t->tp.fasta_out ? '>' : '@';
+        da.lines = t->tp.fasta_out ? 2u : 4u;
+        da.literal_only = t->literal_only ? 1u : 0u;
         hipLaunchKernelGGL(csdefl::deflate_chunks, dim3(t->max_chunks), dim3(256), 0, rs, da);
         csdefl::LayoutArgs la;
         la.info = s.d_chunk[m];

@@ -175,12 +175,19 @@ def test_text_path_errors_are_the_readers_errors():
             assert counts3 == [0, 0, 0] and streams3 == [[b"", b""]] * 3
 
 
+@pytest.mark.parametrize("lz", [True, False])
 @pytest.mark.parametrize("n", [1, 40, 3000, 60_000])
-def test_device_compressed_output_is_gzip_of_the_same_text(n):
+def test_device_compressed_output_is_gzip_of_the_same_text(n, lz, monkeypatch):
     """cs_text_params.compress: every route's output as ONE gzip member written on the device (32 KB deflate blocks with
-    their own Huffman codes, stored blocks where that does not pay: the one-record case) -- any inflater must give
-    back exactly the text the uncompressed form returns, CRC-32 and ISIZE included (Python's gzip checks both)."""
+    their own Huffman codes -- runs and the previous record's name as LZ77 matches, CUTSEQ_GPU_LZ=0: literals only --,
+    stored blocks where that does not pay: the one-record case) -- any inflater must give back exactly the text the
+    uncompressed form returns, CRC-32 and ISIZE included (Python's gzip checks both).  The ratio is pinned: the
+    counterpart of xopen's level-1 writer must not quietly get worse (zlib level 1 on the same text is within a few
+    per cent of the LZ form, profiles/r04_gzip_ratio.json)."""
     import gzip
+    import zlib
+    if not lz:
+        monkeypatch.setenv("CUTSEQ_GPU_LZ", "0")
     scheme = BUILDIN_ADAPTERS["TAKARAV3"]
     st = planmod.CutadaptConfig()
     st.trim_polyA = True
@@ -206,8 +213,13 @@ def test_device_compressed_output_is_gzip_of_the_same_text(n):
                         else:
                             assert packed[route][m] == b""
     if n >= 3000:
-        ratio = sum(len(x) for row in plain for x in row) / sum(len(x) for row in packed for x in row)
-        assert ratio > 2.5, ratio  # Huffman-only: ~2 bits per base / quality value, headers a little over 4
+        raw = sum(len(x) for row in plain for x in row)
+        ratio = raw / sum(len(x) for row in packed for x in row)
+        level1 = raw / sum(len(zlib.compress(x, 1)) + 12 for row in plain for x in row if x)
+        if lz:
+            assert ratio > 0.93 * level1, (ratio, level1)  # within a few per cent of `gzip -1`
+        else:
+            assert ratio > 2.5, ratio  # Huffman-only: ~3 bits per base, 2 per quality value, names a little over 4 per byte
 
 
 @pytest.mark.parametrize("compress,paired,length,short_rows", [(False, True, 8, False), (True, True, 8, False), (False, False, 8, False),

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 TAG=${1:-r03}
 OUT=gpurun_out/round
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 10 --cpu-sample 0 --no-copy-probe > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 10 --cpu-sample 0 --no-copy-probe --tier-pairs 0 > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); cp "$f" $OUT/kernel_stats.csv
 t=$(find $OUT/trace -name "*kernel_trace.csv" | head -1); head -30 "$t" > $OUT/kernel_trace_head.csv
 rm -rf $OUT/trace
@@ -16,7 +16,7 @@ bash tools/pmc.sh > $OUT/pmc.log 2>&1 || { echo "pmc failed"; tail -5 $OUT/pmc.l
 mkdir -p profiles && python3 tools/summarize_pmc.py $TAG > $OUT/pmc_summary.log 2>&1 || { echo "summary failed"; cat $OUT/pmc_summary.log; exit 1; }
 cp profiles/${TAG}_pmc_summary.json $OUT/pmc_summary.json
 timeout -k 10 400 python3 bench.py --traffic-json $OUT/pmc_summary.json > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
-timeout -k 10 200 python3 bench.py --serial --cpu-sample 0 > $OUT/bench_serial.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 200 python3 bench.py --serial --cpu-sample 0 --tier-pairs 0 > $OUT/bench_serial.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config2 --pairs 10000000 --steps 20 --cpu-sample 1000000 > $OUT/bench_config2.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config4 --cpu-sample 500000 > $OUT/bench_config4.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config5 > $OUT/bench_config5.json 2>> $OUT/bench.err || exit 1
