@@ -215,13 +215,14 @@ def test_leading_adapter_pair_in_one_walk(rule, anywhere, monkeypatch):
         assert np.array_equal(g_pair, g_apart)
 
 
-@pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0"])
+@pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_CUT_RUNS=0"])
 @pytest.mark.parametrize("rule", [0, 1])
 @pytest.mark.parametrize("name,flags,paired", CHAIN_CASES)
 def test_chain_presets(name, flags, paired, rule, switch, monkeypatch):
     """Every preset x flag chain; also with the merged walk of the leading adapter pair switched off (CUTSEQ_PAIR=0:
-    existence-only 5' scan + exact 3' filter apart) and with the existence-only scan off as well (CUTSEQ_EXISTS=0:
-    the exact filter for every op) -- the switches are read when the plan is created."""
+    existence-only 5' scan + exact 3' filter apart), with the existence-only scan off as well (CUTSEQ_EXISTS=0: the exact
+    filter for every op) and with one op-loop turn per CUT op instead of one per run of them (CUTSEQ_CUT_RUNS=0) -- the
+    switches are read when the plan is created."""
     if switch:
         monkeypatch.setenv(*switch.split("="))
     scheme = BUILDIN_ADAPTERS.get(name, name)
