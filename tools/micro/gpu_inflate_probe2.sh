@@ -9,5 +9,5 @@ hipcc -O3 --offload-arch=gfx950 -w -o /tmp/gpu_inflate_probe2 tools/micro/gpu_in
 python3 tools/make_fastq.py $N $W/syn > /dev/null 2>&1 || exit 1
 gzip -dc $W/syn_R1.fastq.gz | gzip -1 > $W/single.gz
 ls -la $W/single.gz
-timeout -k 5 300 /tmp/gpu_inflate_probe2 $W/single.gz 1024 256 64
+timeout -k 5 500 /tmp/gpu_inflate_probe2 $W/single.gz ${CHUNKS:-1024 256 64}
 rm -rf $W
