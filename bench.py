@@ -342,6 +342,12 @@ def main():
             "frac_at_mix_ceiling": round(ach / (N_SIMD * clock_hz / VALU_CYCLES_MIX), 4),
             "mix_ceiling_cycles_per_instr": VALU_CYCLES_MIX,
             "valu_insts_per_launch": valu_insts,
+            # per 64-pair tile and kernel (SQ_INSTS_VALU of the same counter passes): the figure instruction-count work is judged on
+            "valu_insts_per_64_pair_tile": {
+                "both": round(valu_insts / (n / 64), 1),
+                "scan": round(scan.get("SQ_INSTS_VALU", {}).get("mean_per_launch", 0) / (n / 64), 1),
+                "resolve": round(counters.get("per_kernel", {}).get("resolve", {}).get("SQ_INSTS_VALU", {}).get("mean_per_launch", 0) / (n / 64), 1),
+            },
             "scan_wait_inst_any_over_wave_cycles": round(wait_inst / wave_cycles, 4) if wait_inst and wave_cycles else None,
             "scan_wait_any_over_wave_cycles": round(wait_any / wave_cycles, 4) if wait_any and wave_cycles else None,
             "source": traffic_source,
