@@ -139,6 +139,11 @@ def _adapter_json(op: AdapterOp, name: str, matches: int) -> dict:
     return d
 
 
+def _host_threads() -> int:
+    from . import fastq
+    return fastq.pool_size()
+
+
 def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, output2, short1, short2,
                 untrimmed1, untrimmed2) -> dict:
     """Same header block as the reference's ``json_report`` (run.py:262-283) followed by the
@@ -149,22 +154,31 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
     filtered = {k: None for k in FILTER_KEYS}
     filtered["too_short"] = totals["routes"][1]
     q1, q2 = _mate_sum(totals, 0, "qualtrim_bp"), (_mate_sum(totals, 1, "qualtrim_bp") if paired else None)
+    engine = {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
+              "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
+              "per_device": totals["stats"],
+              **({"ranks": totals["ranks"], "ranks_split": totals.get("ranks_split"),
+                  "threads_per_rank": totals.get("threads_per_rank")} if totals.get("ranks") else {}),
+              **({"demultiplexed": dict(zip(totals.get("bin_names") or [], totals["routes"][3:]))}
+                 if tp.demux is not None else {})}
+    # Key order as the reference's file has it: its own header dict (tag, cutadapt_version, input, output, barcode),
+    # then ``d.update(stats.as_json())`` -- keys it already holds keep their place and take as_json's value, the others
+    # follow in as_json's order (schema_version, python_version, command_line_arguments, cores, read_counts, ...).
+    # Engine-specific counters come last, under a key cutadapt does not have.
+    import platform
+    import sys
     d = {
         "tag": "Cutadapt report",
-        "schema_version": [0, 3],
         # the report layout is cutadapt 5's; the numbers come from this engine (local version label says so)
         "cutadapt_version": f"5.0+cutseq.amd.{__version__}",
-        "engine": {"name": "cutseq_amd", "version": __version__, "devices": totals.get("devices"),
-                   "seconds": totals.get("seconds"), "is_untrimmed_any": totals["routes"][2] if tp.untrimmed_filter else None,
-                   "per_device": totals["stats"],
-                   **({"ranks": totals["ranks"], "ranks_split": totals.get("ranks_split"),
-                       "threads_per_rank": totals.get("threads_per_rank")} if totals.get("ranks") else {}),
-                   **({"demultiplexed": dict(zip(totals.get("bin_names") or [], totals["routes"][3:]))}
-                      if tp.demux is not None else {})},
         "input": {"path1": input1, "path2": input2, "paired": True if input2 else False},
         "output": {"output1": output1, "output2": output2, "short1": short1, "short2": short2,
                    "untrimmed1": untrimmed1, "untrimmed2": untrimmed2},
         "barcode": barcode.to_dict(),
+        "schema_version": [0, 3],
+        "python_version": platform.python_version(),
+        "command_line_arguments": list(sys.argv[1:]),
+        "cores": totals.get("threads") or _host_threads(),  # (cutadapt: the runner's cores; here: the host pool)
         "read_counts": {
             "input": totals["in_pairs"],
             "filtered": filtered,
@@ -191,6 +205,7 @@ def json_report(tp: TrimPlan, totals: dict, barcode, input1, input2, output1, ou
         "adapters_read2": ([_adapter_json(a2, "2", _matched(totals, 1, s2))] if a2 is not None else []) if paired else None,
         "poly_a_trimmed_read1": None,
         "poly_a_trimmed_read2": None,
+        "engine": engine,
     }
     return d
 
