@@ -612,7 +612,9 @@ def set_threads(n) -> None:
 
 def pool_size() -> int:
     from .synth import usable_cpus
-    cores = max(2, usable_cpus(32))
+    # (the cap: one process with a worker per GPU of an eight-GPU node inflates for all of them -- 32 threads were 20 GB/s
+    # of text, a quarter of what eight text engines take; the GPU boxes' 16-thread share is below either cap)
+    cores = max(2, usable_cpus(128))
     return cores if _THREADS is None else min(cores, _THREADS)
 
 
