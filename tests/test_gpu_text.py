@@ -222,6 +222,50 @@ def test_device_compressed_output_is_gzip_of_the_same_text(n, lz, monkeypatch):
             assert ratio > 2.5, ratio  # Huffman-only: ~3 bits per base, 2 per quality value, names a little over 4 per byte
 
 
+def test_device_gzip_of_tiny_and_repetitive_records():
+    """The device's LZ77 stage at its edges: records of a few bytes (thousands of line ends per 32 KB chunk: more than the
+    chunk's line index holds), empty reads, long homopolymer / single-quality runs that cross the 128-byte slices and the
+    32 KB chunks, names that share nothing and names that are identical.  Whatever the matcher finds, zlib must give
+    back the uncompressed form's bytes."""
+    import gzip
+    import random
+    rng = random.Random(19)
+    scheme = "ACACGACGCTCTTCCGATCT>AGATCGGAAGAGCACACGTC"  # no UMI, no masks: names and reads pass through
+    st = planmod.CutadaptConfig()
+    st.min_length = 0
+    st.min_quality = 0
+    tp = util.compile_plan(scheme, st, False)
+    for style in ("tiny", "runs", "same-names"):
+        reads, names = [], []
+        for i in range(12_000 if style == "tiny" else 3_000):
+            if style == "tiny":
+                n = rng.choice([0, 0, 1, 2, 3])
+                reads.append((util.random_dna(rng, n), "I" * n))
+                names.append(b"r%d" % i)
+            elif style == "runs":
+                n = rng.choice([150, 150, 149, 37])
+                base = rng.choice("ACGT")
+                reads.append((base * n, rng.choice("I9-") * n))
+                names.append(b"%x" % rng.getrandbits(64))
+            else:
+                reads.append((util.random_dna(rng, 150), "I" * 150))
+                names.append(b"INSTRUMENT:123:FLOWCELL:1:1101:10000:20000 1:N:0:ACGT")
+        batch = util.batch_from_reads(reads)
+        text = fastq_text(names, batch.seq1, batch.qual1, batch.len1)
+        n = len(reads)
+        plain, counts = run_text(tp, text, None, n, batch.stride)
+        with TrimEngine(tp, device=0, slots=0) as eng:
+            with textpath.TextEngine(eng, slots=1, max_text_bytes=len(text) + 1024, max_records=n, stride=batch.stride,
+                                     compress=True) as te:
+                packed, counts2 = te.run(text, n, None)
+        assert counts2 == counts
+        for route in range(3):
+            if plain[route][0]:
+                assert gzip.decompress(packed[route][0]) == plain[route][0], (style, route)
+        if style != "tiny":
+            assert sum(len(x[0]) for x in packed) * 4 < sum(len(x[0]) for x in plain), style  # runs and names do compress
+
+
 @pytest.mark.parametrize("compress,paired,length,short_rows", [(False, True, 8, False), (True, True, 8, False), (False, False, 8, False),
                                                               (False, True, 12, False), (True, True, 8, True), (False, True, 12, True)])
 def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired, length, short_rows):
