@@ -542,6 +542,13 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
     const char *env = getenv("CUTSEQ_PAIR");
     const bool allow = coded && !(env && atoi(env) == 0);
     for (int m = 0; m < 2; ++m) {
+      if (allow && cnt[m] >= 1) {  // a forward, free-ended Myers-32 op that opens the chain alone: the same walk, one recurrence
+        csdev::DevOp &f = p->host.ops[m][0];
+        const bool free_ends = (f.op.align_flags & (CS_QUERY_START | CS_QUERY_STOP)) == (CS_QUERY_START | CS_QUERY_STOP);
+        if (f.op.kind == CS_OP_ADAPTER && f.filter_mode == csdev::FILTER_MYERS32 && !f.op.reversed && free_ends &&
+            f.op.shortcut == CS_SHORTCUT_NONE && !f.exists_only)
+          f.solo_first = 1;
+      }
       if (!allow || cnt[m] < 2) continue;
       csdev::DevOp &a = p->host.ops[m][0];
       const csdev::DevOp &b = p->host.ops[m][1];

@@ -32,8 +32,14 @@ def test_config4_exact_bench_scheme_300k_pairs():
     assert (g1["cap_len"] == 8).mean() > 0.99  # the 8-nt UMI behind the inline barcode leaves R1 for the read name
 
 
+@pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0"])
 @pytest.mark.parametrize("workload,n", [("config3", 400_000), ("config2", 500_000)])
-def test_headline_and_single_end_workloads(workload, n):
+def test_headline_and_single_end_workloads(workload, n, switch, monkeypatch):
+    """Both walk the chain's first op(s) in front of the op loop (config 3: the 5' + 3' pair in one walk, config 2: its
+    lone 3' adapter through the same code with one recurrence); CUTSEQ_PAIR=0 sends them through the op loop's own
+    filters instead."""
+    if switch:
+        monkeypatch.setenv(*switch.split("="))
     run_both(workloads.make_plan(workload), workloads.make_batch(workload, n), threads=16)
 
 
