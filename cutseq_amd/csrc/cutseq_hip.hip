@@ -143,6 +143,7 @@ struct cs_engine {
   // tuning knobs, read once from the environment when the engine is created
   uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 1;  // batch knob: see trim_kernel (resolve)
   uint32_t knob_resolve_waves = 4;  // pipelined calls: resolve waves per CU
+  uint32_t knob_item_slots = 0;     // CUTSEQ_ITEM_SLOTS: items per lane in the scan kernel's item log (0: what fits)
   bool knob_units = false;
   uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 50;
 };
@@ -237,7 +238,7 @@ int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
 
 // launch geometry for a given row stride
 struct Geometry {
-  uint32_t tile_rows, lds_stride_dw, col_dwords, lds_bytes;
+  uint32_t tile_rows, lds_stride_dw, col_dwords, lds_bytes, item_slots;
 };
 
 template <int MODE>
@@ -268,6 +269,20 @@ int geometry_for(const cs_engine *eng, uint32_t stride, int mode, Geometry &g) {
                    csdev::kStatWords +
                    96 /* private mask table + slack in front of the tile, next-tile slot, look-ahead pad */;
   if (mode == csdev::MODE_SCAN) words += csdev::kRingRecords * 8;  // queue records waiting for their reservation
+  g.item_slots = 0;
+  if (mode == csdev::MODE_SCAN && eng->coded) {
+    // item log of the leading adapter walk (trim_kernel.hip.inc, ItemLog): 8 + 1 bytes per item and lane.  As many
+    // slots (2..4) as fit without costing a block per CU: LDS is handed out in granules of 1280 bytes on gfx950.
+    const uint32_t per_slot = kTileRows * 9u;
+    const uint32_t base = words * 4;
+    const uint32_t blocks = std::min<uint32_t>(kLdsBudget / ((base + 1279u) / 1280u * 1280u), 4u * eng->waves_per_simd[mode]);
+    const uint32_t room = blocks ? kLdsBudget / blocks / 1280u * 1280u : 0u;
+    uint32_t slots = room > base ? (room - base) / per_slot : 0u;
+    slots = std::max<uint32_t>(2u, std::min<uint32_t>(4u, slots));
+    if (eng->knob_item_slots) slots = eng->knob_item_slots;
+    g.item_slots = slots;
+    words += (slots * per_slot + 3u) / 4u;
+  }
   if (mode == csdev::MODE_RESOLVE) {
     g.col_dwords = eng->col_dwords;
     if (eng->knob_col_bytes / 4 > g.col_dwords) g.col_dwords = eng->knob_col_bytes / 4;
@@ -401,6 +416,7 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
     a.lds_stride_dw = g[mode].lds_stride_dw;
     a.col_dwords = g[mode].col_dwords;
     a.n_table_ops = eng->n_table_ops;
+    a.item_slots = g[mode].item_slots;
     void *kargs[] = {&a};
     hipStream_t st = mode == csdev::MODE_SCAN ? stream : rstream;
     if (mode == csdev::MODE_RESOLVE && rstream != stream) {
@@ -990,6 +1006,10 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     if (v >= 1024 && v <= 32768) eng->knob_col_bytes = (uint32_t)v;
   }
   if (const char *env = getenv("CUTSEQ_BATCH_KNOB")) eng->knob_batch = (uint32_t)atol(env);
+  if (const char *env = getenv("CUTSEQ_ITEM_SLOTS")) {
+    const long v = atol(env);
+    if (v >= 1 && v <= 16) eng->knob_item_slots = (uint32_t)v;
+  }
   if (const char *env = getenv("CUTSEQ_RESOLVE_WAVES")) {
     const long v = atol(env);
     if (v >= 1 && v <= 16) eng->knob_resolve_waves = (uint32_t)v;

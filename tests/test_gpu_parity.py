@@ -215,7 +215,51 @@ def test_leading_adapter_pair_in_one_walk(rule, anywhere, monkeypatch):
         assert np.array_equal(g_pair, g_apart)
 
 
-@pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_CUT_RUNS=0"])
+@pytest.mark.parametrize("slots", ["", "1", "3"])
+@pytest.mark.parametrize("solo", [False, True])
+def test_item_log_of_the_leading_walk_overflows_into_the_queue(solo, slots, monkeypatch):
+    """The leading walk only LOGS the groups of eight columns in which the 3' op has a candidate (trim_kernel.hip.inc,
+    ItemLog: a few slots per lane in LDS) and does the candidate book-keeping behind the loops.  A read with more flagged
+    groups than slots must not be decided there: it goes to the top region of the deferral queue and the resolve kernel
+    filters the chain's first op exactly.  Reads with two to six copies of the 3' adapter (whole, damaged, with indels,
+    overlapping, back to back), pair form (5' + 3' op) and lone form (the 3' op opens the chain); the default log and
+    logs of one and three slots (CUTSEQ_ITEM_SLOTS)."""
+    if slots:
+        monkeypatch.setenv("CUTSEQ_ITEM_SLOTS", slots)
+    rng = random.Random(4242 + solo)
+    p5, p3 = "ACACGACGCTCTTCCGATCT", "AGATCGGAAGAGCACACGTC"
+    total_refiltered = 0
+    for trial in range(3):
+        rate3 = [0.2, 0.1, 0.3][trial]
+        reads = []
+        for _ in range(4000):
+            s = util.random_dna(rng, rng.choice([0, 5, 20, 40]), "ACGT")
+            for _copy in range(rng.choice([1, 2, 2, 3, 4, 6])):
+                s += util.mutate(rng, p3, rng.choice([0, 0, 1, 2, 3, 5]), "ACGT")
+                s += util.random_dna(rng, rng.choice([0, 0, 1, 3, 8, 17, 30]), "ACGT")
+            if rng.random() < 0.2:  # low complexity: the adapter's own first bases over and over
+                s += p3[:7] * rng.randint(1, 6)
+            s = s[: rng.choice([60, 100, 150, 150, 150, 230, 300])]
+            reads.append((s, "I" * len(s)))
+        batch = util.batch_from_reads(reads)
+        ops = []
+        if not solo:
+            ops.append(planmod.AdapterOp("p5", p5[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, rightmost=True,
+                                         match_flag=abi.CS_F_ADAPTER5))
+        ops.append(planmod.AdapterOp("p3", p3, rate3, 3, WHERE["BACK"], abi.CS_REMOVE_AFTER, match_flag=abi.CS_F_ADAPTER3))
+        ops.append(planmod.CutOp(-4))
+        for rule in (0, 1):
+            tp = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                                  select_rule=rule, use_filter=True)
+            run_both(tp, batch)
+            with TrimEngine(tp, device=0, slots=1, max_reads=batch.n, max_stride=batch.stride) as eng:
+                eng.trim(batch.seq1, batch.qual1, batch.len1, None, None, None)
+                total_refiltered += eng.stats()[0].n_refiltered
+    if slots != "3":
+        assert total_refiltered > 1000  # the reads above do overflow a log of one or two slots
+
+
+@pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_CUT_RUNS=0", "CUTSEQ_ITEM_SLOTS=1"])
 @pytest.mark.parametrize("rule", [0, 1])
 @pytest.mark.parametrize("name,flags,paired", CHAIN_CASES)
 def test_chain_presets(name, flags, paired, rule, switch, monkeypatch):
