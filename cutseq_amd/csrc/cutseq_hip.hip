@@ -152,6 +152,17 @@ namespace {
 
 bool is_acgt(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
+// DevOp::f: the op's scalar fields as dwords, for the device (trim_kernel.hip.inc, DevFields).  Called on the copies
+// an engine uploads, when nothing changes the ops any more.
+void sync_fields(csdev::DevOp &d) {
+  const cs_op &o = d.op;
+  csdev::DevFields &f = d.f;
+  f.kind = o.kind, f.align_flags = o.align_flags, f.reversed = o.reversed, f.remove = o.remove, f.shortcut = o.shortcut;
+  f.match_flag = o.match_flag, f.required = o.required, f.conditional = o.conditional, f.capture = o.capture;
+  f.homopolymer = o.homopolymer, f.q_base = o.q_base, f.stat_slot = o.stat_slot, f.m = o.m, f.k = o.k;
+  f.min_overlap = o.min_overlap, f.force_min_len = o.force_min_len, f.cut_len = o.cut_len, f.q_cutoff = o.q_cutoff;
+}
+
 int build_dev_op(const cs_op &in, csdev::DevOp &out, int index, int mate) {
   memset(&out, 0, sizeof out);
   out.op = in;
@@ -936,6 +947,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     csdev::DevPlan dp = plan->host;
     for (int mt = 0; mt < 2; ++mt)
       for (int i = 0; i < plan->host.n_ops[mt]; ++i) {
+        sync_fields(dp.ops[mt][i]);
         if (dp.ops[mt][i].op.kind != CS_OP_DEMUX) continue;
         if (dp.ops[mt][i].filter_mode) {
           // the barcodes' own ops, the table of candidates, the candidate lists: one allocation
@@ -950,7 +962,9 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
           uint8_t *d = nullptr;
           ENG_TRY(hipMalloc(&d, o_pool + dl.pool.size() + 256));
           eng->d_tables.push_back(d);
-          ENG_TRY(hipMemcpy(d, dl.ops.data(), b_ops, hipMemcpyHostToDevice));
+          std::vector<csdev::DevOp> bops = dl.ops;
+          for (csdev::DevOp &bo : bops) sync_fields(bo);
+          ENG_TRY(hipMemcpy(d, bops.data(), b_ops, hipMemcpyHostToDevice));
           ENG_TRY(hipMemcpy(d + o_first, dl.first.data(), b_first, hipMemcpyHostToDevice));
           if (!dl.pool.empty()) ENG_TRY(hipMemcpy(d + o_pool, dl.pool.data(), dl.pool.size(), hipMemcpyHostToDevice));
           dp.ops[mt][i].peq[0] = (uint64_t)(uintptr_t)(d + o_first);
