@@ -69,6 +69,7 @@ N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICRO
 # opcodes of this kernel's mix (shifts left, v_perm, compares: ~15 %) make its own ceiling 2.3 cycles.
 VALU_CYCLES_SPEC, VALU_CYCLES_MIX = 2.0, 2.3
 PARITY_SAMPLE = 200_000  # pairs every rank checks against the oracle when world > 1
+GEN_PIECE = 16_000_000   # pairs generated on the host and uploaded at a time
 
 
 def parse_args():
@@ -76,7 +77,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--pairs", type=int, default=16_000_000, help="read pairs per step (resident batch)")
+    ap.add_argument("--pairs", type=int, default=100_000_000,
+                    help="read pairs per step = the resident batch (default: BASELINE config 3's 100 M pairs, 61 GB of HBM)")
     ap.add_argument("--workload", choices=["config3", "config2", "config4", "config5"], default="config3")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-filter", action="store_true", help="ablation: exact DP on every read")
@@ -178,22 +180,30 @@ def main():
     # every rank trims its own shard of the read stream (weak scaling: world * n reads in all), no exchange step
     first, last = shard.shard_bounds(world * n, rank, world)
     assert last - first == n
-    batch = workloads.make_batch(args.workload, n, first_index=first)  # the generator the parity tests use
-    stride = batch.stride
-
-    def up(a):
-        return torch.from_numpy(a).to(dev, non_blocking=False)
-
-    d = {"seq1": up(batch.seq1), "qual1": up(batch.qual1), "len1": up(batch.len1.view(np.int16))}
-    if paired:
-        d.update(seq2=up(batch.seq2), qual2=up(batch.qual2), len2=up(batch.len2.view(np.int16)))
-    # the host copy is only needed for the CPU legs (baseline sample, parity sample): keep its head, drop ten gigabytes
+    # The resident batch is generated and uploaded in pieces (the generator is keyed by the global pair index: any split
+    # of the range yields the same bytes), so the host never holds more than one piece of a 100 M-pair batch; the head of
+    # the first piece stays for the CPU legs (baseline sample, parity sample, tier data).
     tiers_on = args.tier_pairs > 0 and args.workload == "config3" and world == 1
     keep = min(n, max(args.cpu_sample, PARITY_SAMPLE, args.tier_pairs if tiers_on else 0))
-    for name in ("seq1", "qual1", "len1", "seq2", "qual2", "len2"):
-        arr = getattr(batch, name, None)
-        if arr is not None:
-            setattr(batch, name, arr[:keep].copy())
+    names = ("seq1", "qual1", "len1") + (("seq2", "qual2", "len2") if paired else ())
+    d, batch, stride = {}, None, 0
+    for at in range(0, n, GEN_PIECE):
+        m = min(GEN_PIECE, n - at)
+        piece = workloads.make_batch(args.workload, m, first_index=first + at)  # the generator the parity tests use
+        if batch is None:
+            stride = piece.stride
+            for name in names:
+                arr = getattr(piece, name)
+                shape = (n,) + arr.shape[1:]
+                d[name] = torch.empty(shape, dtype=torch.int16 if name.startswith("len") else torch.uint8, device=dev)
+        for name in names:
+            arr = getattr(piece, name)
+            d[name][at:at + m].copy_(torch.from_numpy(arr.view(np.int16) if name.startswith("len") else arr))
+        if batch is None:
+            batch = piece
+            for name in names:
+                setattr(batch, name, getattr(piece, name)[:keep].copy())
+        del piece
     # one set of result arrays per step in flight (the engine lets a call start once the call three before it is done)
     n_sets = 1 if args.serial else 3
     sets = []
@@ -324,6 +334,32 @@ def main():
         "exact_dp_fraction": round((st1.n_exact_dp + st2.n_exact_dp) / max(1, st1.n_reads + st2.n_reads), 4),
         "refiltered_fraction": round((st1.n_refiltered + st2.n_refiltered) / max(1, st1.n_reads + st2.n_reads), 4),
     }
+    if n > GEN_PIECE and args.workload != "config5":
+        # Full-size property (outside the timed region): the batch-sized launch must give, bit for bit, what launches of
+        # GEN_PIECE reads over the same resident rows give -- the sizes the parity tests hold to the oracle.  (Tile
+        # hand-out in big and small units, queue capacities and reservations all scale with the launch.)
+        pieces_equal = True
+        m_max = min(GEN_PIECE, n)
+        po1 = torch.empty((m_max, 8), dtype=torch.uint8, device=dev)
+        po2 = torch.empty((m_max, 8), dtype=torch.uint8, device=dev) if paired else None
+        esz = d["seq1"].element_size() * stride
+        for at in range(0, n, GEN_PIECE):
+            m = min(GEN_PIECE, n - at)
+            q1 = abi.cs_reads(d["seq1"].data_ptr() + at * esz, d["qual1"].data_ptr() + at * esz, d["len1"].data_ptr() + at * 2,
+                              po1.data_ptr(), None, None)
+            q2 = None
+            if paired:
+                q2 = abi.cs_reads(d["seq2"].data_ptr() + at * esz, d["qual2"].data_ptr() + at * esz,
+                                  d["len2"].data_ptr() + at * 2, po2.data_ptr(), None, None)
+            eng.trim_device(q1, q2, m, stride, stream=sh, pipelined=False)
+            torch.cuda.synchronize(dev)
+            pieces_equal = pieces_equal and bool(torch.equal(po1[:m], out1[at:at + m]))
+            if paired:
+                pieces_equal = pieces_equal and bool(torch.equal(po2[:m], out2[at:at + m]))
+        result["full_size_launch_equals_piecewise_launches"] = pieces_equal
+        if not pieces_equal:
+            result["parity_error"] = "the batch-sized launch differs from launches of GEN_PIECE reads over the same rows"
+        del po1, po2
     if valu_insts:
         # The bound that governs: VALU issue slots, priced with the clock MEASURED in the same counter passes
         # (GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 / kernel duration, MI355X_MICROARCH.md "DVFS give-back").

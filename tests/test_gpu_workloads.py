@@ -92,3 +92,25 @@ def test_config5_96plex_200k_pairs_equal_96_independent_runs():
     assert np.array_equal(g2, o2)
     assert int(gst1.op_matched[2]) == int((bc != abi.CS_DEMUX_NONE).sum())  # op 2 of mate 1 is the demultiplexer
     assert int(gst2.out_bp) == int(ost2.out_bp)
+
+
+def test_one_large_launch_equals_the_same_rows_in_small_launches():
+    """BASELINE config 3 is quoted on ONE resident batch of 100 M pairs (bench.py's default launch; it checks this
+    property itself at full size, ``full_size_launch_equals_piecewise_launches``).  The size-independent form here:
+    3 M pairs in one launch -- 46 875 tiles, big and small hand-out units, every queue reservation path -- against the same
+    rows in launches of 1 M, 1 M and the ragged rest; the first 300 k pairs of it against the oracle."""
+    n = 3_000_017
+    tp = workloads.make_plan("config3")
+    batch = workloads.make_batch("config3", n)
+    with TrimEngine(tp, device=0, slots=1, max_reads=n, max_stride=batch.stride) as eng:
+        w1, _, w2 = eng.trim(batch.seq1, batch.qual1, batch.len1, batch.seq2, batch.qual2, batch.len2)
+        w1, w2 = w1.copy(), w2.copy()
+        for lo, hi in ((0, 1_000_000), (1_000_000, 2_000_000), (2_000_000, n)):
+            p1, _, p2 = eng.trim(batch.seq1[lo:hi], batch.qual1[lo:hi], batch.len1[lo:hi],
+                                 batch.seq2[lo:hi], batch.qual2[lo:hi], batch.len2[lo:hi])
+            assert np.array_equal(p1, w1[lo:hi]) and np.array_equal(p2, w2[lo:hi])
+    a1, n1, a2, n2 = tp.pack()
+    m = 300_000
+    o1, _, _ = oracle.trim_mate(a1, n1, tp.params(), batch.seq1[:m], batch.qual1[:m], batch.len1[:m], threads=16)
+    o2, _, _ = oracle.trim_mate(a2, n2, tp.params(), batch.seq2[:m], batch.qual2[:m], batch.len2[:m], threads=16)
+    assert np.array_equal(w1[:m], o1) and np.array_equal(w2[:m], o2)

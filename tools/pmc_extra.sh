@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmcx
 rm -rf $OUT; mkdir -p $OUT
-run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --serial --steps 3 --warmup 1 --cpu-sample 0 --no-copy-probe > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --pairs 16000000 --serial --steps 3 --warmup 1 --cpu-sample 0 --no-copy-probe --tier-pairs 0 > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run ic SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
 run if SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_SMEM
 run wt SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU

@@ -18,8 +18,8 @@ cp profiles/${TAG}_pmc_summary.json $OUT/pmc_summary.json
 timeout -k 10 400 python3 bench.py --traffic-json $OUT/pmc_summary.json > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 timeout -k 10 200 python3 bench.py --serial --cpu-sample 0 --tier-pairs 0 > $OUT/bench_serial.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 200 python3 bench.py --workload config2 --pairs 10000000 --steps 20 --cpu-sample 1000000 > $OUT/bench_config2.json 2>> $OUT/bench.err || exit 1
-timeout -k 10 200 python3 bench.py --workload config4 --cpu-sample 500000 > $OUT/bench_config4.json 2>> $OUT/bench.err || exit 1
-timeout -k 10 200 python3 bench.py --workload config5 > $OUT/bench_config5.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 200 python3 bench.py --workload config4 --pairs 16000000 --cpu-sample 500000 > $OUT/bench_config4.json 2>> $OUT/bench.err || exit 1
+timeout -k 10 200 python3 bench.py --workload config5 --pairs 16000000 > $OUT/bench_config5.json 2>> $OUT/bench.err || exit 1
 timeout -k 10 400 python3 tools/tiers.py > $OUT/tiers.json 2> $OUT/tiers.err || { echo "tiers failed"; tail -5 $OUT/tiers.err; exit 1; }
 timeout -k 10 400 python3 tools/e2e_bench.py 8000000 > $OUT/e2e.json 2> $OUT/e2e.err || { echo "e2e failed"; tail -5 $OUT/e2e.err; exit 1; }
 bash tools/text_profile.sh > $OUT/text_profile.log 2>&1 || { echo "text profile failed"; tail -5 $OUT/text_profile.log; exit 1; }

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for lib in "$@"; do
   OUT=gpurun_out/valu_ab/$(basename $lib .so); rm -rf $OUT; mkdir -p $OUT
-  CUTSEQ_HIP_LIB=$GRAFT_REPO_ROOT/$lib timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT -- python3 bench.py --serial --steps 3 --warmup 1 --cpu-sample 0 --no-copy-probe > $OUT/log.txt 2>&1
+  CUTSEQ_HIP_LIB=$GRAFT_REPO_ROOT/$lib timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT -- python3 bench.py --pairs 16000000 --serial --steps 3 --warmup 1 --cpu-sample 0 --no-copy-probe --tier-pairs 0 > $OUT/log.txt 2>&1
   python3 - $OUT $lib <<'PY'
 import csv, glob, collections, sys
 agg = collections.defaultdict(list)
