@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc
 rm -rf $OUT && mkdir -p $OUT
-run() { name=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 20 --warmup 10 --cpu-sample 0 --no-copy-probe --tier-pairs 0 > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 20 --warmup 10 --cpu-sample 0 --no-copy-probe --no-piece-check --tier-pairs 0 > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
