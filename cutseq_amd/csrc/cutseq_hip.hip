@@ -568,12 +568,30 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
   {
     const char *env = getenv("CUTSEQ_PAIR");
     const bool allow = coded && !(env && atoi(env) == 0);
+    // The walk LOGS the groups of eight columns that hold a candidate of its exact op in a few LDS slots per lane and
+    // sends a read with more flagged groups than slots through the resolve kernel (trim_kernel.hip.inc, ItemLog).  That
+    // is the rare case for the adapters the reference compiles (20 bases, four errors: a random 150-base read holds a
+    // candidate one time in a thousand); a short adapter with a loose error bound matches random sequence all the
+    // time, and every such read would take the slow road.  Estimate: candidates per 300 random bases ~ 300 * sum over
+    // e <= k of C(m, e) * 6^e / 4^m (three substitutions and about as many indel variants per error); above 3 % the op
+    // keeps the op loop's own filter, which does its book-keeping in place.
+    auto log_friendly = [](int mm, int kk) {
+      double variants = 0, choose = 1, pw = 1;
+      for (int e = 0; e <= kk && e <= mm; ++e) {
+        variants += choose * pw;
+        choose = choose * (double)(mm - e) / (double)(e + 1);
+        pw *= 6.0;
+      }
+      double space = 1;
+      for (int i = 0; i < mm; ++i) space *= 4.0;
+      return 300.0 * variants / space < 0.03;
+    };
     for (int m = 0; m < 2; ++m) {
       if (allow && cnt[m] >= 1) {  // a forward, free-ended Myers-32 op that opens the chain alone: the same walk, one recurrence
         csdev::DevOp &f = p->host.ops[m][0];
         const bool free_ends = (f.op.align_flags & (CS_QUERY_START | CS_QUERY_STOP)) == (CS_QUERY_START | CS_QUERY_STOP);
         if (f.op.kind == CS_OP_ADAPTER && f.filter_mode == csdev::FILTER_MYERS32 && !f.op.reversed && free_ends &&
-            f.op.shortcut == CS_SHORTCUT_NONE && !f.exists_only)
+            f.op.shortcut == CS_SHORTCUT_NONE && !f.exists_only && log_friendly(f.op.m, f.op.k))
           f.solo_first = 1;
       }
       if (!allow || cnt[m] < 2) continue;
@@ -583,7 +601,7 @@ int cs_plan_create(const cs_op *ops_r1, int n1, const cs_op *ops_r2, int n2, con
       const bool ends_free = (b.op.align_flags & (CS_QUERY_START | CS_QUERY_STOP)) == (CS_QUERY_START | CS_QUERY_STOP);
       if (!a.exists_only || a.op.kind != CS_OP_ADAPTER || b.op.kind != CS_OP_ADAPTER || b.exists_only ||
           b.filter_mode != csdev::FILTER_MYERS32 || b.op.reversed || !ends_free || b.op.shortcut != CS_SHORTCUT_NONE ||
-          ma + ka > 31 || ka > 14)
+          ma + ka > 31 || ka > 14 || !log_friendly(b.op.m, b.op.k))
         continue;
       a.pair_next = 1;
       for (int ent = 0; ent < 4; ++ent) {

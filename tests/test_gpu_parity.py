@@ -259,6 +259,33 @@ def test_item_log_of_the_leading_walk_overflows_into_the_queue(solo, slots, monk
         assert total_refiltered > 1000  # the reads above do overflow a log of one or two slots
 
 
+@pytest.mark.parametrize("m3,rate,walks", [(10, 0.2, False), (8, 0.125, False), (13, 0.1, True), (20, 0.2, True)])
+def test_loose_short_adapters_keep_the_op_loops_filter(m3, rate, walks):
+    """A short adapter with a loose error bound finds candidates in random sequence all the time; logged in two LDS slots
+    per lane, nearly every read would overflow into the resolve kernel.  The plan estimates the candidate rate from (m, k)
+    and lets such an op keep the op loop's own filter (cutseq_hip.hip, log_friendly): parity either way, and the share
+    of reads that take the overflow road stays small."""
+    rng = random.Random(31 + m3)
+    p3 = util.random_dna(rng, m3, "ACGT")
+    reads = []
+    for _ in range(20000):
+        s = util.random_dna(rng, rng.choice([40, 90, 150]), "ACGT")
+        if rng.random() < 0.35:
+            s = s[: rng.randint(0, len(s))] + util.mutate(rng, p3, rng.choice([0, 0, 1]), "ACGT") + util.random_dna(rng, 20, "ACGT")
+        s = s[:150]
+        reads.append((s, "I" * len(s)))
+    batch = util.batch_from_reads(reads)
+    ops = [planmod.AdapterOp("p3", p3, rate, 3, WHERE["BACK"], abi.CS_REMOVE_AFTER, match_flag=abi.CS_F_ADAPTER3),
+           planmod.CutOp(-2)]
+    tp = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                          select_rule=0, use_filter=True)
+    run_both(tp, batch)
+    with TrimEngine(tp, device=0, slots=1, max_reads=batch.n, max_stride=batch.stride) as eng:
+        eng.trim(batch.seq1, batch.qual1, batch.len1, None, None, None)
+        refiltered = eng.stats()[0].n_refiltered
+    assert refiltered <= (0.02 * batch.n if walks else 0)
+
+
 @pytest.mark.parametrize("switch", ["", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_CUT_RUNS=0", "CUTSEQ_ITEM_SLOTS=1"])
 @pytest.mark.parametrize("rule", [0, 1])
 @pytest.mark.parametrize("name,flags,paired", CHAIN_CASES)
