@@ -148,3 +148,32 @@ def test_four_slots_in_flight_on_three_lanes():
     for b, (g1, _, g2) in zip(batches, results):
         o1, o2, _, _ = expect(tp, b)
         assert (g1 == o1).all() and (g2 == o2).all()
+
+
+@pytest.mark.parametrize("shift", [2, 4, 6])
+def test_result_arrays_that_are_not_eight_byte_aligned(shift):
+    """cs_result is a struct of halfwords and bytes: the C ABI promises its array two-byte alignment only.  The kernels
+    write a record as ONE eight-byte store where the array allows it and field by field where it does not; both forms
+    must give the same records (scan kernel and resolve kernel write through the same code)."""
+    dev = torch.device("cuda:0")
+    tp = takara_plan()
+    batch = synth.generate_pairs(50_003, 150, first_index=4242, indel_frac=0.3)
+    r = Resident(batch, dev)
+    raw1 = torch.zeros(batch.n * 8 + 8, dtype=torch.uint8, device=dev)
+    raw2 = torch.zeros(batch.n * 8 + 8, dtype=torch.uint8, device=dev)
+    p = [x.data_ptr() for x in r.t]
+    m1 = abi.cs_reads(p[0], p[1], p[2], raw1.data_ptr() + shift, None, None)
+    m2 = abi.cs_reads(p[3], p[4], p[5], raw2.data_ptr() + shift, None, None)
+    stream = torch.cuda.Stream(device=dev)
+    sh = C.c_void_p(stream.cuda_stream)
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        eng.trim_device(r.r1, r.r2, batch.n, batch.stride, stream=sh)
+        eng.trim_device(m1, m2, batch.n, batch.stride, stream=sh)
+        stream.synchronize()
+    g1, g2 = r.results()
+    o1, o2, _, _ = expect(tp, batch)
+    assert (g1 == o1).all() and (g2 == o2).all()
+    for raw, want in ((raw1, g1), (raw2, g2)):
+        got = raw[shift:shift + batch.n * 8].cpu().numpy().view(abi.RESULT_DTYPE).reshape(-1)
+        assert (got == want).all()
+        assert int(raw[:shift].sum()) == 0 and int(raw[shift + batch.n * 8:].sum()) == 0  # nothing outside the array
