@@ -259,6 +259,63 @@ def test_item_log_of_the_leading_walk_overflows_into_the_queue(solo, slots, monk
         assert total_refiltered > 1000  # the reads above do overflow a log of one or two slots
 
 
+@pytest.mark.parametrize("rule", [0, 1])
+def test_anchored_prefix_hits_with_substitutions_settle_in_the_filter(rule):
+    """PrefixAdapter (the inline barcode, cutseq/run.py:357-362, 592-597): with at most two errors a substitution-only
+    hit in column m settles in the filter when column m is the first candidate column and the cheapest (myers_verdict's
+    anchored-start rule).  The reads below crowd its edges: barcodes of 4 to 12 bases, rates that give k = 0..3, copies
+    with substitutions at the first / last base, insertions and deletions next to them (candidates one column to either
+    side, equal and lower scores), repeats of the barcode's own ends behind it, homopolymer and two-letter barcodes,
+    reads barely longer than the barcode, soft-masked bases; both selection rules and both indel tie orders."""
+    import os
+    # (CS_PREFIX_TRIALS / CS_PREFIX_SEED: the same test as a soak with fresh seeds)
+    rng = random.Random(8128 + rule + int(os.environ.get("CS_PREFIX_SEED", "0")))
+    settled = 0
+    for trial in range(int(os.environ.get("CS_PREFIX_TRIALS", "24"))):
+        m = rng.choice([4, 5, 6, 6, 7, 8, 9, 10, 12])
+        alpha = rng.choice(["ACGT", "ACGT", "AC", "A"]) if trial % 4 == 3 else "ACGT"
+        bc = util.random_dna(rng, m, alpha)
+        rate = rng.choice([0.0, 0.12, 0.2, 0.2, 0.25, 0.34])
+        reads = []
+        for _ in range(2500):
+            style = rng.random()
+            core = list(bc)
+            if style < 0.25:  # substitutions only, edges favoured
+                for _e in range(rng.choice([0, 1, 1, 2, 3])):
+                    pos = rng.choice([0, m - 1, rng.randrange(m)])
+                    core[pos] = rng.choice("ACGTN")
+                head = "".join(core)
+            elif style < 0.5:  # one indel at an edge, maybe a substitution elsewhere
+                head = "".join(core)
+                pos = rng.choice([0, 1, m - 1, m])
+                head = head[:pos] + rng.choice("ACGT") + head[pos:] if rng.random() < 0.5 else head[:max(pos - 1, 0)] + head[pos:]
+                if rng.random() < 0.4:
+                    head = util.mutate(rng, head, 1, "ACGT")
+            elif style < 0.7:
+                head = util.mutate(rng, bc, rng.choice([1, 2, 3]), "ACGT")
+            else:
+                head = util.random_dna(rng, m, alpha)
+            tail = rng.choice([bc[-2:], bc[:2], bc, "", bc[-1] * 3]) + util.random_dna(rng, rng.choice([0, 1, 2, 3, 5, 40]), "ACGT")
+            sq = (head + tail)[: rng.choice([m - 1, m, m + 1, m + 2, m + 4, 60, 60])]
+            reads.append((sq, "I" * len(sq)))
+        batch = util.batch_from_reads(reads)
+        util.soft_mask(batch, 0.1, seed=trial)
+        ops = [planmod.AdapterOp("bc", bc, rate, m, WHERE["PREFIX"], abi.CS_REMOVE_BEFORE, match_flag=abi.CS_F_INLINE),
+               planmod.CutOp(2)]
+        tp = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                              select_rule=rule, use_filter=True, indel_tie=rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION]))
+        g1, _ = run_both(tp, batch)
+        tp_full = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                                   select_rule=rule, use_filter=False, indel_tie=tp.indel_tie)
+        f1, _ = run_both(tp_full, batch)  # the exact DP on every read gives the same records
+        assert np.array_equal(g1, f1)
+        with TrimEngine(tp, device=0, slots=1, max_reads=batch.n, max_stride=batch.stride) as eng:
+            eng.trim(batch.seq1, batch.qual1, batch.len1, None, None, None)
+            st = eng.stats()[0]
+            settled += int(st.op_matched[0]) - int(st.n_exact_dp)
+    assert settled > 5000  # many matches never see the DP
+
+
 @pytest.mark.parametrize("m3,rate,walks", [(10, 0.2, False), (8, 0.125, False), (13, 0.1, True), (20, 0.2, True)])
 def test_loose_short_adapters_keep_the_op_loops_filter(m3, rate, walks):
     """A short adapter with a loose error bound finds candidates in random sequence all the time; logged in two LDS slots
