@@ -259,6 +259,63 @@ def test_item_log_of_the_leading_walk_overflows_into_the_queue(solo, slots, monk
         assert total_refiltered > 1000  # the reads above do overflow a log of one or two slots
 
 
+@pytest.mark.parametrize("solo", [False, True])
+@pytest.mark.parametrize("rule", [0, 1])
+def test_hits_one_column_behind_the_first_cheapest_column(rule, solo):
+    """A substitution-only occurrence of the 3' adapter whose LAST base is one of the substitutions costs the same in the
+    column before it (the last base skipped), so the first cheapest column is not the hit's own; myers_verdict settles
+    such a hit one column on when the read's base there differs from the adapter's last base.  The reads crowd that
+    rule: substitutions at the last one to three adapter bases, adapters that end in a repeated base (the rule must
+    stand back), the adapter's last base repeated behind the hit, indels near the end, a second copy close by, soft
+    masks, Ns; adapters of 10 to 28 bases at several rates; both selection rules and tie orders; the walk with and
+    without the 5' op in front."""
+    import os
+    rng = random.Random(5150 + rule + 2 * solo + int(os.environ.get("CS_PREFIX_SEED", "0")))
+    p5 = "ACACGACGCTCTTCCGATCT"
+    for trial in range(int(os.environ.get("CS_PREFIX_TRIALS", "16"))):
+        m = rng.choice([10, 13, 16, 20, 20, 21, 24, 28])
+        p3 = util.random_dna(rng, m, "ACGT")
+        if trial % 3 == 1:
+            p3 = p3[:-1] + p3[-2]  # ends in a repeated base
+        if trial % 5 == 4:
+            p3 = p3[: m // 2] + p3[m // 2 - 1] * (m - m // 2)  # a homopolymer tail
+        rate = rng.choice([0.1, 0.2, 0.2, 0.25, 0.3])
+        reads = []
+        for _ in range(3000):
+            core = list(p3)
+            style = rng.random()
+            if style < 0.55:
+                for pos in rng.sample([m - 1, m - 1, m - 2, m - 3, rng.randrange(m), rng.randrange(m)], rng.choice([1, 1, 2, 3])):
+                    core[pos] = rng.choice("ACGTN")
+                hit = "".join(core)
+            elif style < 0.75:
+                hit = "".join(core)
+                pos = rng.choice([m - 1, m - 2, m, rng.randrange(m)])
+                hit = hit[:pos] + rng.choice("ACGT") + hit[pos:] if rng.random() < 0.5 else hit[:max(pos - 1, 0)] + hit[pos:]
+                hit = util.mutate(rng, hit, rng.choice([0, 1]), "ACGT")
+            else:
+                hit = util.mutate(rng, p3, rng.choice([0, 1, 2, 4]), "ACGT")
+            behind = rng.choice(["", p3[-1], p3[-1] * 2, p3[:3], util.random_dna(rng, 2, "ACGT")]) + \
+                util.random_dna(rng, rng.choice([0, 1, 5, 30]), "ACGT")
+            if rng.random() < 0.1:
+                behind = behind[:2] + util.mutate(rng, p3, 1, "ACGT") + behind[2:]
+            sq = util.random_dna(rng, rng.choice([0, m + 3, 40, 70, 100]), "ACGT") + hit + behind
+            sq = sq[: rng.choice([60, 100, 150, 150])]
+            reads.append((sq, "I" * len(sq)))
+        batch = util.batch_from_reads(reads)
+        util.soft_mask(batch, 0.1, seed=trial)
+        ops = []
+        if not solo:
+            ops.append(planmod.AdapterOp("p5", p5[::-1], 0.2, 10, WHERE["BACK"], abi.CS_REMOVE_BEFORE, rightmost=True,
+                                         match_flag=abi.CS_F_ADAPTER5))
+        ops.append(planmod.AdapterOp("p3", p3, rate, 3, WHERE["BACK"], abi.CS_REMOVE_AFTER, match_flag=abi.CS_F_ADAPTER3))
+        ops.append(planmod.CutOp(-3))
+        tie = rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION])
+        tp = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                              select_rule=rule, use_filter=True, indel_tie=tie)
+        run_both(tp, batch)
+
+
 @pytest.mark.parametrize("rule", [0, 1])
 def test_anchored_prefix_hits_with_substitutions_settle_in_the_filter(rule):
     """PrefixAdapter (the inline barcode, cutseq/run.py:357-362, 592-597): with at most two errors a substitution-only
