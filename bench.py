@@ -415,7 +415,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0 and args.workload != "config5":
         # (config 5 has no single CPU counterpart: its parity definition is 96 oracle runs, tests/test_gpu_workloads.py)
         import oracle  # the checker, timed as the CPU baseline; never part of the product path
-        m = min(args.cpu_sample, n)
+        m = min(args.cpu_sample, n, batch.seq1.shape[0])  # (the host keeps the head of the first generated piece)
         threads = oracle.host_threads()
         a1, n1, a2, n2 = tp.pack()
         params = tp.params()
