@@ -7,4 +7,4 @@ without the HIP library and a gfx950 device the engine raises.
 """
 from .common import BUILDIN_ADAPTERS, BarcodeConfig, BarcodeSeq, reverse_complement  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.5.0"  # the one version source: pyproject.toml reads it (tool.setuptools.dynamic), `cutseq -V` prints it

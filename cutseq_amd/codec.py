@@ -260,8 +260,8 @@ class GzipSource:
             yield arr, nbytes
 
     def indexed_blocks(self, start: int = 0) -> Iterator[tuple]:
-        """(compressed offset at which the block's first member starts, buffer, nbytes); the offset is -1 when the
-        stream cannot be entered anywhere but at its start (one huge member, no libdeflate).  What the multi-process
+        """(compressed offset at which the block's first member starts, buffer, nbytes); the offset is -1 for a block
+        in whose front the stream cannot be entered (the second and later blocks of one huge member; no libdeflate).  What the multi-process
         form of the CLI (``ranks.py``) builds its split points from."""
         if self.map is None:
             return
@@ -487,11 +487,10 @@ class GzipSource:
                     out = self.take(cap)
                     continue
                 break
-            if rc == 3:  # one very large member: stream it (and whatever follows) through zlib
-                self.give(out)
-                for arr, nbytes in self._zlib_stream(pos):
-                    yield -1, arr, nbytes
-                return
+            if rc == 3:  # one very large member: stream IT through zlib, then go on member by member (a reader
+                self.give(out)  # with a stop offset -- a rank's share, textio._members_until -- needs real offsets again)
+                pos = yield from self._from_head(self._zlib_member(pos), pos)
+                continue
             if rc != 0:
                 self.give(out)
                 raise OSError(f"{self.path}: corrupt gzip data (libdeflate error {rc})")
@@ -507,12 +506,25 @@ class GzipSource:
         H = _pinflate() if self.pool is not None else None
         hdr = _gzip_header_size(self.map, head) if H is not None else 0
         if H is None or hdr == 0 or os.environ.get("CUTSEQ_PARALLEL_INFLATE", "1") == "0":
-            for arr, nbytes in self._zlib_stream(head):
-                yield -1, arr, nbytes
-            return
-        end = yield from self._parallel_member(H, head + hdr)
+            end = yield from self._from_head(self._zlib_member(head), head)
+        else:
+            end = yield from self._from_head(self._parallel_member(H, head + hdr), head)
         if end < self.size:
             yield from self._members(end)
+
+    @staticmethod
+    def _from_head(gen, head: int):
+        """The blocks of one big member: the FIRST one carries the member's own start offset (a reader with a stop
+        offset sees where it is), the others stay -1 (nobody can enter there)."""
+        first = True
+        while True:
+            try:
+                item = next(gen)
+            except StopIteration as done:
+                return done.value
+            if first:
+                item, first = (head,) + tuple(item[1:]), False
+            yield item
 
     def _parallel_member(self, H, dstart: int):
         """Generator over the blocks of the deflate stream that starts at byte ``dstart``; returns the file offset behind
@@ -660,7 +672,21 @@ class GzipSource:
         return tail + 8
 
     # -- fallback: zlib streaming, any member size -------------------------------------------------
-    def _zlib_stream(self, start: int) -> Iterator[tuple]:
+    def _zlib_member(self, start: int):
+        """Generator over the (-1, buffer, nbytes) blocks of the ONE member at ``start``, through zlib; returns the file
+        offset behind its trailer, where the member-by-member walk goes on with real offsets (a rank whose share ends
+        there must not read on into the next rank's members: ADVICE r4)."""
+        end = start
+        for item in self._zlib_stream(start, single=True):
+            if isinstance(item, int):
+                end = item
+            else:
+                yield -1, item[0], item[1]
+        return end
+
+    def _zlib_stream(self, start: int, single: bool = False) -> Iterator[tuple]:
+        """(buffer, nbytes) blocks of everything from ``start`` to the end of the file; ``single``: of the member at
+        ``start`` only, followed by one int -- the offset behind that member."""
         import numpy as np
         buf, n = self.map, self.size
         pos = start
@@ -671,6 +697,8 @@ class GzipSource:
             pos += len(data)
             while data:
                 if fresh and data[0] == 0 and not any(data) and not any(buf[pos:min(n, pos + (1 << 20))]):
+                    if single:
+                        yield n
                     return  # zero padding behind the last member
                 try:
                     out = d.decompress(data, _STREAM_BLOCK)
@@ -681,12 +709,17 @@ class GzipSource:
                     yield np.frombuffer(out, dtype=np.uint8), len(out)
                 if d.eof:
                     data = d.unused_data
+                    if single:
+                        yield pos - len(data)
+                        return
                     d = zlib.decompressobj(31)
                     fresh = True
                 else:
                     data = d.unconsumed_tail
         if not fresh:
             raise OSError(f"{self.path}: truncated gzip stream")
+        if single:
+            yield n
 
 
 def is_gzip(path: str) -> bool:

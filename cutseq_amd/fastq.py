@@ -637,7 +637,7 @@ class OutputFile:
     def __init__(self, path: str, level: int = 1):
         self.path = path
         self.level = level
-        self.gz = path.endswith(".gz")
+        self.gz = path.lower().endswith(".gz")
         self.fh = open(path, "wb")
         self.q: "queue.Queue" = queue.Queue(maxsize=16)
         self.err: Optional[BaseException] = None

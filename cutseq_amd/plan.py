@@ -187,6 +187,7 @@ Op = Union[AdapterOp, CutOp, QTrimOp, DemuxOp]
 class MateChain:
     ops: List[Op] = field(default_factory=list)
     name_suffixes: Sequence[str] = ()  # SuffixRemover literals, applied in order
+    rename_at: Optional[int] = None  # ops in front of the (PairedEnd)Renamer in the reference's modifier list
 
     def describe(self) -> List[str]:
         lines = [f"SuffixRemover({s!r})" for s in self.name_suffixes]
@@ -392,6 +393,7 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     if barcode.umi3.len > 0:
         cap += 1
         ops.append(CutOp(-barcode.umi3.len, capture=cap))
+    rename_at = len(ops)  # the Renamer sits here in the reference's list (run.py:377-380)
     # step 6: masks
     if barcode.mask5.len > 0:
         ops.append(CutOp(barcode.mask5.len))
@@ -417,7 +419,7 @@ def compile_single(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
         else:
             logging.warning("Library is not (-) strand, but --auto-rc is enabled. Ignored.")
     return TrimPlan(
-        r1=MateChain(ops, (".1", "/1")),
+        r1=MateChain(ops, (".1", "/1"), rename_at),
         r2=None,
         has_umi=barcode.umi5.len + barcode.umi3.len > 0,
         min_length=settings.min_length,
@@ -466,6 +468,7 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
     if barcode.umi3.len > 0:
         o1.append(CutOp(-barcode.umi3.len, conditional=cond, force_min_len=fmin))
         o2.append(CutOp(barcode.umi3.len, capture=1))
+    rename_at = len(o1)  # the PairedEndRenamer sits here in the reference's list (run.py:642-645)
     # step 6
     if barcode.mask5.len > 0:
         o1.append(CutOp(barcode.mask5.len))
@@ -497,8 +500,8 @@ def compile_paired(barcode: BarcodeConfig, settings: CutadaptConfig, untrimmed_r
         else:
             logging.warning("Library is not (-) strand, but --auto-rc is enabled. Ignored.")
     return TrimPlan(
-        r1=MateChain(o1, (".1", "/1")),
-        r2=MateChain(o2, (".2", "/2")),
+        r1=MateChain(o1, (".1", "/1"), rename_at),
+        r2=MateChain(o2, (".2", "/2"), rename_at),
         has_umi=barcode.umi5.len + barcode.umi3.len > 0,
         min_length=settings.min_length,
         untrimmed_filter=untrimmed_filter,

@@ -72,8 +72,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="Automatically reverse complement reads if the library strand is '-'. "
                         "For paired-end, R1 and R2 will be swapped.")
     p.add_argument("-t", "--threads", type=int, default=None,
-                   help="Number of host threads for FASTQ parsing, formatting and (de)compression "
-                        "(Default: all usable cores; the per-read work runs on the GPU).")
+                   help="Number of host threads for reading, (de)compression and writing. The reference's -t "
+                        "(default 1) is the number of cutadapt worker PROCESSES that do the per-read work; here that "
+                        "work runs on the GPU(s), so -t only bounds the host I/O pool and the output does not depend "
+                        "on it. -t 1 is accepted and means one host thread. (Default: all usable cores)")
     p.add_argument("-n", "--dry-run", action="store_true",
                    help="Print the sequence of modifier steps instead of running the pipeline.")
     p.add_argument("-V", "--version", action="version", version=f"%(prog)s {__version__}")
@@ -198,21 +200,33 @@ def compile_plan(args, barcode: BarcodeConfig, settings: CutadaptConfig) -> Trim
         untrimmed_requested=args.untrimmed_file[0] is not None and args.untrimmed_file[1] is not None)
 
 
-def dry_run(tp: TrimPlan, barcode: BarcodeConfig):
+def dry_run_steps(tp: TrimPlan) -> List[str]:
+    """The reference's modifier list in ITS order (cutseq/run.py:326-426, 533-731): the two SuffixRemovers, the
+    adapter and UMI steps, the (PairedEnd)Renamer right behind the UMI step (run.py:377-380, 642-645), then masks,
+    poly-A, quality trimming (and the single-end reverse complement).  The text of a step is this build's own
+    (cutadapt's ``repr``s are not available here); the ORDER is the reference's."""
     if tp.paired:
+        steps = [f"({a}, {b})" for a, b in zip(tp.r1.describe(), tp.r2.describe())]
+        renamer = f"PairedEndRenamer({'{id}_{r1.cut_prefix}{r2.cut_prefix}' if tp.has_umi else '{id}'!r})"
+    else:
+        steps = list(tp.r1.describe())
+        renamer = f"Renamer({'{id}_{cut_prefix}{cut_suffix}' if tp.has_umi else '{id}'!r})"
+    at = len(tp.r1.ops) if tp.r1.rename_at is None else tp.r1.rename_at
+    steps.insert(len(tp.r1.name_suffixes) + at, renamer)
+    if not tp.paired and tp.reverse_complement:
+        steps.append("ReverseComplementConverter()")
+    return steps
+
+
+def dry_run(tp: TrimPlan, barcode: BarcodeConfig):
+    if tp.paired:  # run.py:734-749: the parts through print, the steps through logging
         for b in ["p5", "p7", "inline5", "inline3", "umi5", "umi3", "mask5", "mask3", "strand"]:
             print(f"{b}: {getattr(barcode, b)}")
-        steps1, steps2 = tp.r1.describe(), tp.r2.describe()
-        i = 0
-        for i, (a, b) in enumerate(zip(steps1, steps2), 1):
-            logging.info(f"Step {i}: ({a}, {b})")
-        logging.info(f"Step {i + 1}: PairedEndRenamer({'{id}_{r1.cut_prefix}{r2.cut_prefix}' if tp.has_umi else '{id}'!r})")
-    else:
-        for i, a in enumerate(tp.r1.describe(), 1):
-            print(f"Step {i}: {a}")
-        print(f"Step {i + 1}: Renamer({'{id}_{cut_prefix}{cut_suffix}' if tp.has_umi else '{id}'!r})")
-        if tp.reverse_complement:
-            print(f"Step {i + 2}: ReverseComplementConverter()")
+        for i, step in enumerate(dry_run_steps(tp), 1):
+            logging.info(f"Step {i}: {step}")
+    else:  # run.py:429-432
+        for i, step in enumerate(dry_run_steps(tp), 1):
+            print(f"Step {i}: {step}")
 
 
 class _DeviceWorker(threading.Thread):

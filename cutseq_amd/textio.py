@@ -751,7 +751,7 @@ def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
         bin_files = list(getattr(args, "demux_files", None) or []) if n_bins else []
         names_all = [n for group in [args.output_file if not n_bins else [], args.short_file, args.untrimmed_file] + bin_files
                      for n in group if n]
-        compress = bool(names_all) and all(n.endswith(".gz") for n in names_all) and os.environ.get("CUTSEQ_GPU_DEFLATE", "1") != "0"
+        compress = bool(names_all) and all(n != "-" and codec.container_of_name(n) == "gzip" for n in names_all) and os.environ.get("CUTSEQ_GPU_DEFLATE", "1") != "0"
         if r2 is not None and r1.fasta != r2.fasta:
             raise fastq.FastqFormatError("the two input files are in different formats (one FASTA, one FASTQ)")
         fasta_out = output_format(names_all, has_qualities=not r1.fasta)

@@ -293,9 +293,10 @@ typedef struct cs_text_params {
   uint8_t has_umi;            /* Renamer template carries the captures: {id}_{cut_prefix}{cut_suffix}           */
   uint8_t untrimmed_filter;   /* IsUntrimmedAny filter installed (run.py:453-467, 771-784)                      */
   uint8_t reverse_complement; /* single-end --auto-rc on a '-' library (run.py:420-426)                         */
-  uint8_t compress;           /* 1: every route's output leaves the device as ONE gzip member (32 KB deflate blocks,
-                                 dynamic Huffman codes, no LZ77 stage; the counterpart of xopen's level-1 writer the
-                                 reference's OutputFiles use): route_bytes / out_bytes then count compressed bytes    */
+  uint8_t compress;           /* 1: every route's output leaves the device as ONE gzip member (32 KB deflate blocks with
+                                 their own dynamic Huffman codes behind an LZ77 stage -- byte runs and the previous
+                                 record's name as matches, bases as literals; the counterpart of xopen's level-1 writer
+                                 the reference's OutputFiles use): route_bytes / out_bytes then count compressed bytes  */
   uint32_t max_tag;           /* most bytes a record name can gain: 1 + the plan's capture lengths (0 = no UMI) */
   const char *suffix1[2];     /* SuffixRemover literals of mate 1, applied in order (NULL = none)               */
   const char *suffix2[2];

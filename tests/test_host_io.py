@@ -183,6 +183,55 @@ def test_cli_dry_run_lists_the_chain(capsys):
     assert "p5: ACACGACGCTCTTCCGATCT (AGATCGGAAGAGCGTCGTGT)" in out and "strand: -" in out
 
 
+def _step_kinds(tp):
+    """The kind of every --dry-run step (per mate for paired plans), in the order they are printed."""
+    import re as _re
+    names = ("SuffixRemover", "RightmostFrontAdapter", "BackAdapter", "PrefixAdapter", "SuffixAdapter",
+             "NonInternalBackAdapter", "NonInternalFrontAdapter", "UnconditionalCutter", "ConditionalCutter",
+             "PairedEndRenamer", "Renamer", "QualityTrimmer", "ReverseComplementConverter")
+    pat = _re.compile(r"\b(" + "|".join(names) + r")\(")
+    return [tuple(pat.findall(step)) for step in cli.dry_run_steps(tp)]
+
+
+def test_dry_run_prints_the_renamer_where_the_reference_has_it():
+    """The reference's modifier list holds the (PairedEnd)Renamer right behind the UMI step and in front of the mask
+    steps (cutseq/run.py:377-380 single-end, 642-645 paired), and --dry-run prints that list (run.py:429-432,
+    747-748).  TAKARAV3 (UMI + masks), INLINE (inline barcode + two UMIs) and TAKARAV2 (no UMI)."""
+    st = planmod.CutadaptConfig()
+    S, R5, B3 = ("SuffixRemover",), ("RightmostFrontAdapter",), ("BackAdapter",)
+    U, C, Q = ("UnconditionalCutter",), ("ConditionalCutter",), ("QualityTrimmer",)
+    pair = lambda a, b: a + b
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)   # XXX<XXXXXXNNNNNNNN: umi3 8, mask5 3, mask3 6
+    assert _step_kinds(tp) == [pair(S, S), pair(S, S), pair(R5, R5), pair(B3, B3), pair(C, U), ("PairedEndRenamer",),
+                               pair(U, C), pair(C, U), pair(Q, Q)]  # the renamer is step 6 of 9
+    tp = util.compile_plan(BUILDIN_ADAPTERS["INLINE"], st, True)     # NNNNN>NNNNN(ATCACG): inline3, umi5 5, umi3 5
+    assert _step_kinds(tp) == [pair(S, S), pair(S, S), pair(R5, R5), pair(B3, B3), U + ("PrefixAdapter",), pair(U, C),
+                               pair(C, U), ("PairedEndRenamer",), pair(Q, Q)]
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV2"], st, True)   # XXX<XXX: no UMI -> the renamer follows step 3
+    assert _step_kinds(tp) == [pair(S, S), pair(S, S), pair(R5, R5), pair(B3, B3), ("PairedEndRenamer",), pair(U, C),
+                               pair(C, U), pair(Q, Q)]
+    assert "'{id}'" in cli.dry_run_steps(tp)[4] and "{r1.cut_prefix}" not in cli.dry_run_steps(tp)[4]
+    # single-end: all cuts unconditional, Renamer in front of the masks, the reverse complement last (run.py:373-386, 420-426)
+    st.auto_rc = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, False)
+    assert _step_kinds(tp) == [S, S, R5, B3, U, ("Renamer",), U, U, Q, ("ReverseComplementConverter",)]
+    tp = util.compile_plan(BUILDIN_ADAPTERS["INLINE"], st, False)    # strand '+': --auto-rc is ignored
+    assert _step_kinds(tp) == [S, S, R5, B3, ("SuffixAdapter",), U, U, ("Renamer",), Q]
+    tp = util.compile_plan(BUILDIN_ADAPTERS["SMALLRNA"], st, False)
+    assert _step_kinds(tp) == [S, S, R5, B3, ("Renamer",), Q]
+
+
+def test_one_version_source(capsys):
+    """`cutseq -V`, the package attribute and the packaging metadata name ONE version."""
+    import cutseq_amd
+    with pytest.raises(SystemExit):
+        cli.main(["-V"])
+    assert capsys.readouterr().out.strip() == f"cutseq {cutseq_amd.__version__}"
+    text = (util.GOLDEN.parent.parent / "pyproject.toml").read_text()
+    assert 'dynamic = ["version"]' in text and 'attr = "cutseq_amd.__version__"' in text
+    assert "\nversion = \"" not in text.split("[tool.")[0]
+
+
 # ---------------------------------------------------------------- reports (run.py:222-302, 489, 810)
 
 
@@ -969,3 +1018,38 @@ def test_progress_writes_one_done_line_like_the_reference(monkeypatch):
     p.update(10)
     p.close()
     assert buf.getvalue() == ""
+
+
+def test_a_ranks_share_ends_at_its_member_even_through_the_zlib_fallback(tmp_path, monkeypatch):
+    """two concatenated members too large for one libdeflate call (`cat L001.fq.gz L002.fq.gz`), parallel
+    inflate off -> the zlib fallback.  It used to decode on across the member boundary to the end of the file with
+    offsets of -1, so a rank whose share ended at the boundary also emitted the next rank's records.  Now the fallback
+    stops behind ITS member and the walk goes on with real offsets."""
+    from cutseq_amd import codec, textio
+    a = b"".join(b"@a%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(60_000))
+    b = b"".join(b"@b%d\nTTGTACGTAC\n+\nFFFFFFFFFF\n" % i for i in range(50_000))
+    za, zb = gzip.compress(a, 1), gzip.compress(b, 1)
+    path = tmp_path / "two.fq.gz"
+    path.write_bytes(za + zb)
+    monkeypatch.setattr(codec, "_MEMBER_CAP", 1 << 20)  # neither ~1.5 MB member fits one call
+    for env in ({"CUTSEQ_PARALLEL_INFLATE": "0"}, {}, {"CUTSEQ_OWN_INFLATE": "0", "CUTSEQ_PARALLEL_INFLATE": "0"}):
+        for key in ("CUTSEQ_PARALLEL_INFLATE", "CUTSEQ_OWN_INFLATE"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        for pool in (fastq._pool(), None):
+            def share(start, stop):
+                src = codec.GzipSource(str(path), pool)
+                try:
+                    return b"".join(bytes(memoryview(arr)[:n]) for arr, n in textio.TextReader._members_until(src, start, stop))
+                finally:
+                    src.close()
+            assert share(0, len(za)) == a, (env, pool)
+            assert share(len(za), len(za) + len(zb)) == b, (env, pool)
+            src = codec.GzipSource(str(path), pool)
+            offs = [off for off, arr, n in src.indexed_blocks()]
+            src.close()
+            assert len(za) in offs or offs.count(-1) == len(offs)  # real offsets again behind the first member ...
+            src = codec.GzipSource(str(path), pool)
+            assert b"".join(bytes(memoryview(arr)[:n]) for arr, n in src.blocks()) == a + b  # ... and nothing lost
+            src.close()
