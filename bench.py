@@ -56,7 +56,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from cutseq_amd import abi, shard, workloads  # noqa: E402
+from cutseq_amd import abi, shard, synth, workloads  # noqa: E402
 from cutseq_amd.build import kernel_source_hash  # noqa: E402
 from cutseq_amd.engine import TrimEngine  # noqa: E402
 from cutseq_amd.workloads import READ_LEN  # noqa: E402
@@ -88,6 +88,8 @@ def parse_args():
                     help="skip the piecewise launches behind the timed region (profiling runs: per-kernel averages stay clean)")
     ap.add_argument("--tier-pairs", type=int, default=4_000_000,
                     help="pairs of the tier T / tier E legs behind the timed region (config3, one GPU; 0 = skip)")
+    ap.add_argument("--host-generator", action="store_true",
+                    help="generate the batch on the host and upload it in pieces (rounds 1-4; default: on the device)")
     ap.add_argument("--traffic-json", type=str, default=str(default_traffic_json()),
                     help="JSON with HBM bytes per launch measured in separate rocprofv3 --pmc passes (tools/pmc.sh)")
     return ap.parse_args()
@@ -150,6 +152,21 @@ def self_launch(n_ranks: int) -> int:
     return code
 
 
+def device_identity(index: int) -> dict:
+    """Name, uuid and PCI bus id of the device a rank runs on (two ranks on one device must be visible in the line)."""
+    out = {"index": index, "pid": os.getpid()}
+    try:
+        props = torch.cuda.get_device_properties(index)
+        out["name"] = props.name
+        for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id", "gcnArchName"):
+            val = getattr(props, key, None)
+            if val is not None:
+                out[key] = str(val)
+    except Exception as exc:  # the identity must never take the bench line down
+        out["error"] = f"{type(exc).__name__}: {exc}"
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -182,30 +199,43 @@ def main():
     # every rank trims its own shard of the read stream (weak scaling: world * n reads in all), no exchange step
     first, last = shard.shard_bounds(world * n, rank, world)
     assert last - first == n
-    # The resident batch is generated and uploaded in pieces (the generator is keyed by the global pair index: any split
-    # of the range yields the same bytes), so the host never holds more than one piece of a 100 M-pair batch; the head of
-    # the first piece stays for the CPU legs (baseline sample, parity sample, tier data).
+    # The resident batch is generated ON THE DEVICE (the generator is keyed by the global pair index: csrc/synth_device.hip
+    # writes what csrc/cutseq_host.c writes, tests/test_gpu_synth.py): no host buffer of the batch's size, no pageable
+    # copy, start-up independent of the number of ranks.  The host only generates the head of the shard that the CPU
+    # legs need (baseline sample, parity sample, tier data) -- and that head is compared with the device's bytes.
+    # config 5 plants its barcodes with numpy: it keeps the host generator, in pieces.
     tiers_on = args.tier_pairs > 0 and args.workload == "config3" and world == 1
     keep = min(n, max(args.cpu_sample, PARITY_SAMPLE, args.tier_pairs if tiers_on else 0))
     names = ("seq1", "qual1", "len1") + (("seq2", "qual2", "len2") if paired else ())
-    d, batch, stride = {}, None, 0
-    for at in range(0, n, GEN_PIECE):
-        m = min(GEN_PIECE, n - at)
-        piece = workloads.make_batch(args.workload, m, first_index=first + at)  # the generator the parity tests use
-        if batch is None:
-            stride = piece.stride
+    stride = synth._stride_for(READ_LEN)
+    d = {name: torch.empty((n,) if name.startswith("len") else (n, stride),
+                           dtype=torch.int16 if name.startswith("len") else torch.uint8, device=dev) for name in names}
+    t_gen = time.perf_counter()
+    if args.workload == "config5" or args.host_generator:
+        batch = None
+        for at in range(0, n, GEN_PIECE):
+            m = min(GEN_PIECE, n - at)
+            piece = workloads.make_batch(args.workload, m, first_index=first + at)
+            assert piece.stride == stride
             for name in names:
                 arr = getattr(piece, name)
-                shape = (n,) + arr.shape[1:]
-                d[name] = torch.empty(shape, dtype=torch.int16 if name.startswith("len") else torch.uint8, device=dev)
-        for name in names:
-            arr = getattr(piece, name)
-            d[name][at:at + m].copy_(torch.from_numpy(arr.view(np.int16) if name.startswith("len") else arr))
-        if batch is None:
-            batch = piece
-            for name in names:
-                setattr(batch, name, getattr(piece, name)[:keep].copy())
-        del piece
+                d[name][at:at + m].copy_(torch.from_numpy(arr.view(np.int16) if name.startswith("len") else arr))
+            if batch is None:
+                batch = piece
+                for name in names:
+                    setattr(batch, name, getattr(piece, name)[:keep].copy())
+            del piece
+        generator = "host (csrc/cutseq_host.c), uploaded in pieces"
+        head_equal = None
+    else:
+        ptrs = [d[name].data_ptr() for name in names] + [None] * (6 - len(names))
+        assert workloads.fill_device(args.workload, n, ptrs, first_index=first) == stride
+        batch = workloads.make_batch(args.workload, keep, first_index=first)  # the generator the parity tests use
+        torch.cuda.synchronize(dev)
+        head_equal = all(bool(torch.equal(d[name][:keep].cpu(), torch.from_numpy(
+            getattr(batch, name).view(np.int16) if name.startswith("len") else getattr(batch, name)))) for name in names)
+        generator = "device (csrc/synth_device.hip), one launch over the shard's global indices"
+    gen_s = time.perf_counter() - t_gen
     # one set of result arrays per step in flight (the engine lets a call start once the call three before it is done)
     n_sets = 1 if args.serial else 3
     sets = []
@@ -256,8 +286,30 @@ def main():
     assert timed_calls == args.steps, (timed_calls, args.steps)
     scan_ms, resolve_ms = scan_ms_total / args.steps, resolve_ms_total / args.steps
     kernel_ms = [scan_ms + resolve_ms] if args.serial else [scan_ms]
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        # what a reader of the N-GPU line will ask: did every rank run at the same rate, and on its own device?
+        # (gathered with the collective backend itself; the data path has no collective)
+        comm_dev = "cpu" if rehearsal else dev
+        mine = torch.tensor([elapsed / args.steps * 1e3, scan_ms, resolve_ms, gen_s], dtype=torch.float64, device=comm_dev)
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        ident = [None] * world
+        dist.all_gather_object(ident, device_identity(gpu_index))
+        rows = [[float(x) for x in r.cpu()] for r in rows]
+        step_ms = sorted(r[0] for r in rows)
+        per_rank = {
+            "ms_per_step": {"min": round(step_ms[0], 4), "median": round(float(np.median(step_ms)), 4), "max": round(step_ms[-1], 4),
+                            "each": [round(r[0], 4) for r in rows]},
+            "scan_kernel_ms": [round(r[1], 4) for r in rows],     # HIP events around the scan kernel on each rank's stream
+            "resolve_kernel_ms": [round(r[2], 4) for r in rows],
+            "generator_seconds": [round(r[3], 2) for r in rows],
+            "devices": ident,                                      # name / uuid / PCI bus id each rank ran on
+            "distinct_devices": len({(i or {}).get("uuid") or (i or {}).get("pci_bus_id") or k for k, i in enumerate(ident)}),
+            "rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
+            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if not rehearsal else None,
+        }
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -333,9 +385,15 @@ def main():
             "kernel_ms_avg_each": {"scan": round(scan_ms, 4), "resolve": round(resolve_ms, 4)},
             "bytes_per_unit": bytes_per_unit,
         },
+        "batch_generator": {"where": generator, "seconds": round(gen_s, 2), "host_head_pairs": keep,
+                            "device_bytes_equal_host_bytes_on_head": head_equal},
         "exact_dp_fraction": round((st1.n_exact_dp + st2.n_exact_dp) / max(1, st1.n_reads + st2.n_reads), 4),
         "refiltered_fraction": round((st1.n_refiltered + st2.n_refiltered) / max(1, st1.n_reads + st2.n_reads), 4),
     }
+    if head_equal is False:
+        result["parity_error"] = "the device generator's bytes differ from the host generator's on the head of the shard"
+    if per_rank is not None:
+        result["per_rank"] = per_rank
     if n > GEN_PIECE and args.workload != "config5" and not args.no_piece_check:
         # Full-size property (outside the timed region): the batch-sized launch must give, bit for bit, what launches of
         # GEN_PIECE reads over the same resident rows give -- the sizes the parity tests hold to the oracle.  (Tile

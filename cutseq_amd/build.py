@@ -61,6 +61,22 @@ def build_host(force: bool = False) -> Path:
     return HOST_OUT
 
 
+SYNTH_SRC = HERE / "csrc" / "synth_device.hip"
+SYNTH_DEPS = (SYNTH_SRC, HERE.parent / "include" / "cutseq_synth.h")
+SYNTH_OUT = HERE / "libcutseq_synth.so"
+
+
+def build_synth(force: bool = False) -> Path:
+    """The synthetic generator's device form (bench / test infrastructure, its own library: the trimming library
+    carries no generator)."""
+    if not force and SYNTH_OUT.exists() and SYNTH_OUT.stat().st_mtime >= max(p.stat().st_mtime for p in SYNTH_DEPS):
+        return SYNTH_OUT
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", str(SYNTH_OUT), str(SYNTH_SRC)]
+    subprocess.run(cmd, check=True, cwd=str(SYNTH_SRC.parent))
+    return SYNTH_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
     print(build_host(force="--force" in sys.argv))
+    print(build_synth(force="--force" in sys.argv))

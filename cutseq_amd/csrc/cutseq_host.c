@@ -15,24 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-typedef struct csh_synth_params {
-  uint32_t read_len;
-  uint32_t stride;
-  uint64_t seed;
-  uint64_t first_index;
-  const char *p5_fw, *p7_fw, *p5_rc, *p7_rc; /* NUL-terminated */
-  const char *inline5, *inline3;
-  int32_t umi5, umi3, mask5, mask3;
-  int32_t strand; /* +1, -1, 0 */
-  int32_t single_end;
-  double adapter_fraction; /* inserts shorter than the read: 3' adapter visible             */
-  double partial_fraction; /* inserts that leave only a 3..19 nt adapter prefix in the read */
-  double poly_fraction;    /* poly-A/T stretch of 10..40 nt at the insert end                */
-  double art5_fraction;    /* 5' adapter artefact in front of the read                       */
-  double sub_rate;         /* per-base substitution                                          */
-  double indel_frac;       /* reads with an adapter that get one indel inside it             */
-  double n_rate;           /* per-base N                                                     */
-} csh_synth_params;
+#include "../../include/cutseq_synth.h" /* csh_synth_params: one definition for the host and the device form */
 
 typedef struct {
   uint64_t s;

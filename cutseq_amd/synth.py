@@ -102,6 +102,72 @@ def _stride_for(read_len: int) -> int:
     return (read_len + 3) // 4 * 4
 
 
+def _params(bc: BarcodeConfig, read_len: int, stride: int, seed: int, first_index: int, single_end: bool,
+            adapter_fraction: float, partial_fraction: float, poly_fraction: float, art5_fraction: float,
+            sub_rate: float, indel_frac: float, n_rate: float) -> _SynthParams:
+    p = _SynthParams()
+    p.read_len, p.stride, p.seed = read_len, stride, seed & 0xFFFFFFFFFFFFFFFF
+    p.first_index = first_index
+    p.p5_fw, p.p7_fw = bc.p5.fw.upper().encode(), bc.p7.fw.upper().encode()
+    p.p5_rc, p.p7_rc = bc.p5.rc.upper().encode(), bc.p7.rc.upper().encode()
+    p.inline5, p.inline3 = bc.inline5.fw.upper().encode(), bc.inline3.fw.upper().encode()
+    p.umi5, p.umi3, p.mask5, p.mask3 = bc.umi5.len, bc.umi3.len, bc.mask5.len, bc.mask3.len
+    p.strand = {"+": 1, "-": -1, None: 0}[bc.strand]
+    p.single_end = 1 if single_end else 0
+    p.adapter_fraction, p.partial_fraction, p.poly_fraction = adapter_fraction, partial_fraction, poly_fraction
+    p.art5_fraction, p.sub_rate, p.indel_frac, p.n_rate = art5_fraction, sub_rate, indel_frac, n_rate
+    return p
+
+
+def _scheme_config(scheme) -> BarcodeConfig:
+    if scheme is None:
+        from .common import BUILDIN_ADAPTERS
+        scheme = BUILDIN_ADAPTERS["TAKARAV3"]
+    return scheme if isinstance(scheme, BarcodeConfig) else BarcodeConfig(scheme)
+
+
+SYNTH_LIB_PATH = Path(__file__).with_name("libcutseq_synth.so")
+_synth_dev = None
+
+
+def synth_lib() -> C.CDLL:
+    """The generator's DEVICE form (csrc/synth_device.hip, include/cutseq_synth.h): same bytes as the host form,
+    written straight into device arrays.  Bench / test infrastructure; the trimming library does not link it."""
+    global _synth_dev
+    if _synth_dev is None:
+        with _host_lock:
+            if _synth_dev is None:
+                if not SYNTH_LIB_PATH.exists():
+                    raise RuntimeError(f"{SYNTH_LIB_PATH.name} is not built: python -m cutseq_amd.build")
+                L = C.CDLL(str(SYNTH_LIB_PATH))
+                L.csd_synth_pairs.restype = C.c_int
+                L.csd_synth_pairs.argtypes = [C.POINTER(_SynthParams), C.c_uint64] + [C.c_void_p] * 7
+                L.csd_last_error.restype = C.c_char_p
+                L.csd_abi_version.restype = C.c_int
+                _synth_dev = L
+    return _synth_dev
+
+
+def generate_pairs_device(n: int, ptrs, read_len: int = 150, scheme: str | BarcodeConfig | None = None,
+                          seed: int = DEFAULT_SEED, single_end: bool = False,
+                          adapter_fraction: float = 0.35, partial_fraction: float = 0.09,
+                          poly_fraction: float = 0.02, art5_fraction: float = 0.001,
+                          sub_rate: float = 0.01, indel_frac: float = 0.03, n_rate: float = 0.007,
+                          first_index: int = 0, stride: int | None = None, stream=None) -> int:
+    """:func:`generate_pairs` into DEVICE arrays: ``ptrs`` = (seq1, qual1, len1, seq2, qual2, len2) device addresses
+    (the mate-2 entries None for single-end batches) of ``[n][stride]`` byte rows / ``[n]`` uint16 lengths on the current
+    device.  Enqueued on ``stream`` (a hipStream_t address; None = the default stream), not waited for.  -> stride"""
+    bc = _scheme_config(scheme)
+    stride = _stride_for(read_len) if stride is None else stride
+    p = _params(bc, read_len, stride, seed, first_index, single_end, adapter_fraction, partial_fraction, poly_fraction,
+                art5_fraction, sub_rate, indel_frac, n_rate)
+    L = synth_lib()
+    rc = L.csd_synth_pairs(C.byref(p), n, *[C.c_void_p(int(x)) if x else None for x in ptrs], stream)
+    if rc != 0:
+        raise ValueError(f"csd_synth_pairs: {L.csd_last_error().decode()}")
+    return stride
+
+
 def generate_pairs(n: int, read_len: int = 150, scheme: str | BarcodeConfig | None = None,
                    seed: int = DEFAULT_SEED, chunk_index: int = 0, single_end: bool = False,
                    adapter_fraction: float = 0.35, partial_fraction: float = 0.09,
@@ -111,10 +177,7 @@ def generate_pairs(n: int, read_len: int = 150, scheme: str | BarcodeConfig | No
     """Generate ``n`` pairs (or single reads) of ``read_len`` bases.
 
     Pair ``i`` of the call is global pair ``first_index + i`` (default ``chunk_index << 32``)."""
-    if scheme is None:
-        from .common import BUILDIN_ADAPTERS
-        scheme = BUILDIN_ADAPTERS["TAKARAV3"]
-    bc = scheme if isinstance(scheme, BarcodeConfig) else BarcodeConfig(scheme)
+    bc = _scheme_config(scheme)
     stride = _stride_for(read_len)
     if out is None:
         def mk():
@@ -124,17 +187,8 @@ def generate_pairs(n: int, read_len: int = 150, scheme: str | BarcodeConfig | No
         b = (None, None, None) if single_end else mk()
         out = SynthBatch(a[0], a[1], a[2], b[0], b[1], b[2])
     assert out.seq1.shape == (n, stride)
-    p = _SynthParams()
-    p.read_len, p.stride, p.seed = read_len, stride, seed & 0xFFFFFFFFFFFFFFFF
-    p.first_index = (chunk_index << 32) if first_index is None else first_index
-    p.p5_fw, p.p7_fw = bc.p5.fw.upper().encode(), bc.p7.fw.upper().encode()
-    p.p5_rc, p.p7_rc = bc.p5.rc.upper().encode(), bc.p7.rc.upper().encode()
-    p.inline5, p.inline3 = bc.inline5.fw.upper().encode(), bc.inline3.fw.upper().encode()
-    p.umi5, p.umi3, p.mask5, p.mask3 = bc.umi5.len, bc.umi3.len, bc.mask5.len, bc.mask3.len
-    p.strand = {"+": 1, "-": -1, None: 0}[bc.strand]
-    p.single_end = 1 if single_end else 0
-    p.adapter_fraction, p.partial_fraction, p.poly_fraction = adapter_fraction, partial_fraction, poly_fraction
-    p.art5_fraction, p.sub_rate, p.indel_frac, p.n_rate = art5_fraction, sub_rate, indel_frac, n_rate
+    p = _params(bc, read_len, stride, seed, (chunk_index << 32) if first_index is None else first_index, single_end,
+                adapter_fraction, partial_fraction, poly_fraction, art5_fraction, sub_rate, indel_frac, n_rate)
     if threads is None:
         threads = usable_cpus()
     rc = host_lib().csh_synth_pairs(

@@ -108,3 +108,17 @@ def make_batch(workload: str, n: int, first_index: int = 0, threads: Optional[in
     if workload == "config2":
         return synth.generate_single_adapter(n, READ_LEN, first_index=first_index, threads=threads)
     raise ValueError(f"unknown workload {workload!r}")
+
+
+def fill_device(workload: str, n: int, ptrs, first_index: int = 0, stream=None) -> int:
+    """:func:`make_batch` written straight into device arrays by the generator's device form (same bytes as the host
+    form for the same global indices; ``ptrs`` as :func:`synth.generate_pairs_device` takes them) -> row stride.
+    config 5 plants its barcodes with numpy on the host and keeps the host form."""
+    if workload == "config4":
+        return synth.generate_pairs_device(n, ptrs, READ_LEN, CONFIG4_SCHEME, first_index=first_index, stream=stream)
+    if workload == "config3":
+        return synth.generate_pairs_device(n, ptrs, READ_LEN, first_index=first_index, stream=stream)
+    if workload == "config2":
+        return synth.generate_pairs_device(n, ptrs, READ_LEN, "ACACGACGCTCTTCCGATCT>AGATCGGAAGAGC", single_end=True,
+                                           poly_fraction=0.0, art5_fraction=0.0, first_index=first_index, stream=stream)
+    raise ValueError(f"no device generator for workload {workload!r}")

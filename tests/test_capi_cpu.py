@@ -29,6 +29,30 @@ def test_exports_every_declared_symbol(lib):
     assert lib.cs_abi_version() == abi.CS_ABI_VERSION
 
 
+def test_synth_libraries_export_what_their_header_declares():
+    """include/cutseq_synth.h: the generator's host form lives in libcutseq_host.so, its device form in
+    libcutseq_synth.so (loads without a GPU; no compute call here), and ctypes sees the parameter block as C does."""
+    import subprocess, tempfile
+    from cutseq_amd import build, synth
+    build.build_host()
+    build.build_synth()
+    header = (ROOT / "include" / "cutseq_synth.h").read_text()
+    declared = set(re.findall(r"\b(cs[hd]_[a-z0-9_]+)\s*\(", header))
+    assert declared == {"csh_synth_pairs", "csd_synth_pairs", "csd_last_error", "csd_abi_version"}
+    host, dev = synth.host_lib(), synth.synth_lib()
+    for name in declared:
+        assert hasattr(host if name.startswith("csh_") else dev, name), name
+    assert dev.csd_abi_version() == 1
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "cutseq_synth.h"\nint main(void){printf("%zu %zu %zu\\n", ' \
+          'sizeof(csh_synth_params), offsetof(csh_synth_params, umi5), offsetof(csh_synth_params, n_rate)); return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "p.c").write_text(src)
+        subprocess.run(["gcc", "-I", str(ROOT / "include"), "-o", f"{d}/p", f"{d}/p.c"], check=True)
+        got = list(map(int, subprocess.run([f"{d}/p"], check=True, capture_output=True, text=True).stdout.split()))
+    P = synth._SynthParams
+    assert got == [C.sizeof(P), P.umi5.offset, P.n_rate.offset]
+
+
 def test_struct_layout_matches_header():
     # compile-time truth from the C side: build a tiny probe with the same header
     import subprocess, tempfile

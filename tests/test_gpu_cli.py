@@ -368,6 +368,17 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(launcher):
     assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["value"] > 0
     assert rep["config"]["parallelism"] == "shard2" and rep["config"]["pairs_per_step_per_gpu"] == 300000
     assert "cpu_baseline" not in rep  # rank 0 at N = 1 only
+    # what a reader of an N-GPU line asks of it: every rank's step time and event-timed scan kernel,
+    # the device each rank ran on, the world as the collective backend reports it, the per-rank parity gate
+    pr = rep["per_rank"]
+    assert len(pr["ms_per_step"]["each"]) == 2 and pr["ms_per_step"]["min"] <= pr["ms_per_step"]["median"] <= pr["ms_per_step"]["max"]
+    assert abs(pr["ms_per_step"]["max"] - rep["ms_per_step"]) < 1e-3  # the line's figure is the slowest rank's
+    assert len(pr["scan_kernel_ms"]) == 2 and all(x > 0 for x in pr["scan_kernel_ms"]) and len(pr["resolve_kernel_ms"]) == 2
+    assert pr["rccl_world"] == 2 and pr["backend"] == "gloo"  # (the rehearsal's backend; RCCL on a real node)
+    assert len(pr["devices"]) == 2 and all("MI355X" in dv.get("name", "") or dv.get("name") for dv in pr["devices"])
+    assert len({dv["pid"] for dv in pr["devices"]}) == 2 and pr["distinct_devices"] == 1  # two ranks on GPU 0: visible
+    assert rep["all_ranks_identical"] is True
+    assert rep["batch_generator"]["where"].startswith("device") and rep["batch_generator"]["device_bytes_equal_host_bytes_on_head"] is True
 
 
 @pytest.mark.parametrize("layout", ["plain+gz", "gz-members-in-lockstep", "gz-members-out-of-step"])
