@@ -63,16 +63,19 @@ def quality_trim_index(qualities: str, cutoff_back: int, base: int = 33) -> int:
 
 
 def trim_mate(ops, n_ops: int, params: abi.cs_params, seq: np.ndarray, qual: np.ndarray, lens: np.ndarray,
-              want_cap2: bool = False, threads: int = 1):
+              want_cap2: bool = False, threads: int = 1, out: np.ndarray | None = None):
     """Run one mate's batch through the C oracle.
 
-    seq/qual: uint8 [n, stride] C-contiguous, lens: uint16 [n].
+    seq/qual: uint8 [n, stride] C-contiguous, lens: uint16 [n].  ``out``: a RESULT_DTYPE array [n] to fill (callers
+    that run thousands of plans over one batch reuse it: fresh pages cost more than the alignments of short reads).
     Returns (results[RESULT_DTYPE], cap2 | None, cs_stats).
     """
     assert seq.dtype == np.uint8 and qual.dtype == np.uint8 and lens.dtype == np.uint16
     assert seq.flags.c_contiguous and qual.flags.c_contiguous and seq.shape == qual.shape
     n, stride = seq.shape
-    out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    if out is None:
+        out = np.zeros(n, dtype=abi.RESULT_DTYPE)
+    assert out.dtype == abi.RESULT_DTYPE and out.shape == (n,) and out.flags.c_contiguous
     cap2 = np.zeros(n, dtype=abi.CAP2_DTYPE) if want_cap2 else None
     st = abi.cs_stats()
     rc = lib().cs_oracle_trim_mt(C.cast(ops, C.c_void_p), n_ops, C.byref(params), seq.ctypes.data,
