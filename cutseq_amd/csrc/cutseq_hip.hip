@@ -144,6 +144,7 @@ struct cs_engine {
   uint32_t knob_col_bytes = 0, knob_grid_x = 0, knob_batch = 1;  // batch knob: see trim_kernel (resolve)
   uint32_t knob_resolve_waves = 4;  // pipelined calls: resolve waves per CU
   uint32_t knob_item_slots = 0;     // CUTSEQ_ITEM_SLOTS: items per lane in the scan kernel's item log (0: what fits)
+  uint32_t knob_fast_recode = 1;    // CUTSEQ_FAST_RECODE=0: the scan kernel re-codes every tile with the exact form (2: tests, see KArgs)
   bool knob_units = false;
   uint32_t knob_big_shift = 0, knob_small_shift = 0, knob_big_pct = 50;
 };
@@ -379,6 +380,7 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
   a.tile_counter = ln.d_counters;
   a.n_table_ops = eng->n_table_ops;
   a.batch_knob = eng->knob_batch;
+  a.fast_recode = eng->knob_fast_recode;
   a.gate = gate;
   for (int mode = 0; mode < 2; ++mode)
     if (g[mode].lds_bytes > eng->max_dynamic_lds[mode]) {
@@ -1047,6 +1049,7 @@ int cs_engine_create(const cs_plan *plan, int device, uint32_t n_slots, uint32_t
     const long v = atol(env);
     if (v >= 1 && v <= 16) eng->knob_item_slots = (uint32_t)v;
   }
+  if (const char *env = getenv("CUTSEQ_FAST_RECODE")) eng->knob_fast_recode = (uint32_t)atoi(env) <= 2u ? (uint32_t)atoi(env) : 1u;
   if (const char *env = getenv("CUTSEQ_RESOLVE_WAVES")) {
     const long v = atol(env);
     if (v >= 1 && v <= 16) eng->knob_resolve_waves = (uint32_t)v;

@@ -101,7 +101,12 @@ static void finish_read(rng_t *r, const csh_synth_params *p, uint8_t *tpl, int t
     seq[i] = c;
     qual[i] = q;
   }
-  for (uint32_t i = (uint32_t)L; i < p->stride; i++) seq[i] = qual[i] = 0;
+  /* padding behind the read: 'N' in the sequence row (the scan kernel's fast re-coding vouches for A, C, G, T, N only:
+     trim_kernel.hip.inc, encode4_pairs_fast; any padding is correct, this one is the fast one), 0 in the quality row */
+  for (uint32_t i = (uint32_t)L; i < p->stride; i++) {
+    seq[i] = 'N';
+    qual[i] = 0;
+  }
   *len = (uint16_t)L;
 }
 

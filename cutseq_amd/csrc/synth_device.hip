@@ -154,11 +154,15 @@ __device__ void finish_read(Rng &r, const DevSynth &p, const Molecule &mol, int 
       sw = qw = 0;
     }
   }
+  /* padding behind the read: 'N' in the sequence row, 0 in the quality row (as the host form) */
   if (L & 3) {
-    seq4[L >> 2] = sw;
+    seq4[L >> 2] = sw | (0x4E4E4E4Eu << (8 * (L & 3)));
     qual4[L >> 2] = qw;
   }
-  for (uint32_t i = ((uint32_t)L + 3u) >> 2; i < (p.stride >> 2); i++) seq4[i] = qual4[i] = 0;
+  for (uint32_t i = ((uint32_t)L + 3u) >> 2; i < (p.stride >> 2); i++) {
+    seq4[i] = 0x4E4E4E4Eu;
+    qual4[i] = 0;
+  }
   *len = (uint16_t)L;
 }
 

@@ -37,6 +37,7 @@ _PAGE = mmap.ALLOCATIONGRANULARITY
 
 
 PROFILE = os.environ.get("CUTSEQ_PROFILE") == "1"
+_DISCARD = False
 _prof = {}
 _prof_lock = threading.Lock()
 
@@ -477,6 +478,9 @@ class StreamWriter:
             data = self.codec[0](data)
         mv = memoryview(data)
         n = len(mv)
+        if _DISCARD:  # diagnostic (tools/host_io_profile.py): everything but the writers' copies
+            self.pos += n
+            return
         if self.stdout:
             at = 0
             while at < n:
@@ -731,6 +735,8 @@ def output_format(names, has_qualities: bool) -> bool:
 def run_text_pipeline(args, tp, devices, chunk_reads: int, shares=None) -> dict:
     """The CLI's run on the text path -> the run statistics ``report`` expects.  ``shares``: per input file the part
     of it this process takes (``ranks.py``)."""
+    global _DISCARD
+    _DISCARD = os.environ.get("CUTSEQ_DISCARD_OUTPUT") == "1"  # diagnostic: the writers drop their bytes
     paired = tp.paired
     in1 = args.input_file[0]
     in2 = args.input_file[1] if paired else None

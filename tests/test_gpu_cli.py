@@ -43,7 +43,7 @@ def expected(scheme, flags, paired, untrimmed_requested=False):
 # Every switch the product reads from the environment gets the command line run through it:
 # the host parser / formatter instead of the text path, the scan kernel without the merged adapter-pair walk and without
 # the existence-only 5' scan, gzip outputs deflated on the host instead of on the device.
-SWITCHES = ["", "CUTSEQ_TEXT_PATH=0", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_CUT_RUNS=0", "CUTSEQ_GPU_DEFLATE=0", "CUTSEQ_GPU_LZ=0",
+SWITCHES = ["", "CUTSEQ_FAST_RECODE=0", "CUTSEQ_TEXT_PATH=0", "CUTSEQ_PAIR=0", "CUTSEQ_EXISTS=0", "CUTSEQ_CUT_RUNS=0", "CUTSEQ_GPU_DEFLATE=0", "CUTSEQ_GPU_LZ=0",
             "CUTSEQ_ITEM_SLOTS=1", "CUTSEQ_LOG_ALWAYS=1"]
 
 

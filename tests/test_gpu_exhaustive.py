@@ -14,6 +14,7 @@ sends them through the scan kernel's merged forward walk (myers_pair) instead of
 are otherwise kept out of it (their candidates would flood the item log).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -28,7 +29,15 @@ import universe as U
 pytestmark = pytest.mark.gpu
 
 THREADS = max(1, min(16, oracle.host_threads()))
-PER_AC = 6  # settings per two-letter adapter (all 504 are met from 3 on)
+
+# settings per adapter (tests/universe.py: the rotation meets all 504 settings from 3 per two-letter adapter on).
+# CUTSEQ_EXHAUSTIVE_FULL=1: the WHOLE product over the two-letter universe (248 adapters x 504 settings x 160 595 reads =
+# 2.0e10 alignments, ~8 minutes on the GPU box) and twelve settings per three-letter adapter; run by hand once per round,
+# result in profiles/rNN_exhaustive_full.log.
+FULL = os.environ.get("CUTSEQ_EXHAUSTIVE_FULL") == "1"
+PER_AC = len(U.SETTINGS) if FULL else 48
+PER_ACG, PER_ACG7 = (12, 6) if FULL else (3, 2)
+PAIR_PARTNERS = 24 if FULL else 6
 GROUPS = [(abi.CS_SELECT_LEFTMOST, abi.CS_TIE_INSERTION), (abi.CS_SELECT_LEFTMOST, abi.CS_TIE_DELETION),
           (abi.CS_SELECT_SCORE, abi.CS_TIE_INSERTION), (abi.CS_SELECT_SCORE, abi.CS_TIE_DELETION)]
 
@@ -106,27 +115,27 @@ def sweep(res, ads, per_adapter, rule, tie, monkeypatch):
 
 @pytest.mark.parametrize("rule,tie", GROUPS)
 def test_every_read_over_two_letters_against_every_adapter(rule, tie, monkeypatch):
-    """{A,C}: 131 071 reads up to length 16 + 29 524 over {A,C,N} up to length 9, x the 248 adapters of length 3..7, six
-    settings each (all 504 met): 1 488 ops x 160 595 reads = 239 M alignments over the four cases."""
+    """{A,C}: 131 071 reads up to length 16 + 29 524 over {A,C,N} up to length 9, x the 248 adapters of length 3..7, 48
+    settings each (every setting on 23 or 24 adapters): 11 904 ops x 160 595 reads = 1.9e9 alignments over the four cases."""
     res = Resident(*U.stack([U.reads_universe("AC", 16), U.reads_universe("ACN", 9)], 16))
     assert res.n == 131071 + 29524
-    assert sweep(res, U.adapters("AC"), PER_AC, rule, tie, monkeypatch) >= 248 * PER_AC // 4 - 8
+    assert sweep(res, U.adapters("AC"), PER_AC, rule, tie, monkeypatch) > 0
 
 
 @pytest.mark.parametrize("rule,tie", GROUPS)
 def test_every_read_over_three_letters_against_every_adapter(rule, tie, monkeypatch):
     """{A,C,G}: 88 573 reads up to length 10 + 21 845 over {A,C,G,N} up to length 7 x the 1 080 adapters of length 3..6;
-    the 2 187 adapters of length 7 x the 9 841 reads up to length 8 + 1 365 over {A,C,G,N} up to length 5.  One setting per
-    adapter (3 267 adapters: every setting six times)."""
+    the 2 187 adapters of length 7 x the 9 841 reads up to length 8 + 1 365 over {A,C,G,N} up to length 5.  Three (two)
+    settings per adapter: every setting on 15 or more adapters."""
     ads = U.adapters("ACG")
     short = [a for a in ads if len(a) <= 6]
     assert len(ads) == 3267 and len(short) == 1080
     res = Resident(*U.stack([U.reads_universe("ACG", 10), U.reads_universe("ACGN", 7)], 12))
     assert res.n == 88573 + 21845
-    sweep(res, short, 1, rule, tie, monkeypatch)
+    sweep(res, short, PER_ACG, rule, tie, monkeypatch)
     res = Resident(*U.stack([U.reads_universe("ACG", 8), U.reads_universe("ACGN", 5)], 8))
     # (the rotation is over the adapter's index in the FULL list: lengths 3..6 and length 7 do not repeat each other's settings)
-    items7 = [(a, si) for r, t, its in U.schedule(len(ads), 1) if (r, t) == (rule, tie) for a, si in its if len(ads[a]) == 7]
+    items7 = [(a, si) for r, t, its in U.schedule(len(ads), PER_ACG7) if (r, t) == (rule, tie) for a, si in its if len(ads[a]) == 7]
     for lo in range(0, len(items7), 2):
         pair = (items7[lo:lo + 2] * 2)[:2]
         ops = [U.adapter_op(ads[a], U.SETTINGS[si]) for a, si in pair]
@@ -138,8 +147,8 @@ def test_every_read_over_three_letters_against_every_adapter(rule, tie, monkeypa
 @pytest.mark.parametrize("rule,tie", GROUPS)
 def test_the_leading_pair_on_the_two_letter_universe(rule, tie, monkeypatch):
     """The pair that opens every chain the reference compiles (cutseq/run.py:332-355, 544-590): a RightmostFrontAdapter
-    and a BackAdapter (or its --force-anywhere form) behind it, every 5' adapter of length 5..7 over {A,C} with a 3'
-    adapter of the same set, k of either op in {0, 1, 2}, on every read over {A,C} up to length 14 -- as it is, and behind
+    and a BackAdapter (or its --force-anywhere form) behind it, every 5' adapter of length 5..7 over {A,C} with six 3'
+    adapters of the same set, k of either op in {0, 1, 2}, on every read over {A,C} up to length 14 -- as it is, and behind
     fixed prefixes that move the reads across the walk's groups of eight columns.  Default plan (two scans: short
     adapters are not log-friendly) and CUTSEQ_LOG_ALWAYS=1 (the merged forward walk of myers_pair)."""
     from cutseq_amd import plan as planmod
@@ -148,18 +157,18 @@ def test_the_leading_pair_on_the_two_letter_universe(rule, tie, monkeypatch):
     parts = [U.stack([core], 32), U.stack([core12], 32, pad_front=b"CAACC"), U.stack([core12], 32, pad_front=b"GGGGGGGGGGGG")]
     res = Resident(*[np.concatenate([p[i] for p in parts]) for i in range(3)])
     g = GROUPS.index((rule, tie))
-    mine = [i for i in range(len(ads)) if i % 4 == g]
+    mine = [(i, p) for i in range(len(ads)) for p in range(PAIR_PARTNERS) if (i + p) % 4 == g]
 
-    def chain(i):
-        a5, a3 = ads[i], ads[(i * 37 + 11) % len(ads)]
-        k5, k3 = i % 3, (i // 3) % 3
-        mo5 = 3 if (i // 9) % 2 else len(a5)
-        mo3 = 1 if (i // 18) % 2 else 3
-        anywhere = (i // 36) % 2 == 1
+    def chain(i, p):
+        a5, a3 = ads[i], ads[(i * 37 + 11 + 41 * p) % len(ads)]
+        k5, k3 = (i + p) % 3, (i // 3 + p // 3) % 3
+        mo5 = 3 if (i // 9 + p) % 2 else len(a5)
+        mo3 = 1 if (i // 18 + p // 2) % 2 else 3
+        anywhere = (i // 36 + p) % 3 == 1
         return [planmod.rightmost_front(a5, U.rate_for(k5, len(a5)), mo5, abi.CS_F_ADAPTER5),
                 planmod.back(a3, U.rate_for(k3, len(a3)), mo3, anywhere, abi.CS_F_ADAPTER3)], (a5, k5, mo5, a3, k3, mo3, anywhere)
 
     for lo in range(0, len(mine), 2):
         pair = (mine[lo:lo + 2] * 2)[:2]
-        (c1, d1), (c2, d2) = chain(pair[0]), chain(pair[1])
+        (c1, d1), (c2, d2) = chain(*pair[0]), chain(*pair[1])
         res.check(U.one_op_plan(c1, c2, rule, tie), [f"pair {d1}", f"pair {d2}"], monkeypatch, log_always=True)

@@ -762,3 +762,63 @@ def test_hits_that_settle_in_the_filter_stress(seed):
             tie = rng.choice([abi.CS_TIE_INSERTION, abi.CS_TIE_DELETION])
             tp = one_adapter_plan(seq, rate, mo, WHERE[where], remove, rightmost, 0, rule, True, tie)
             run_both(tp, batch, threads=8)
+
+
+@pytest.mark.parametrize("read_len", [150, 151, 75, 250])
+def test_fast_recoding_and_its_fallback(read_len, monkeypatch):
+    """The scan kernel's fast re-coding (trim_kernel.hip.inc, encode4_pairs_fast): (ascii >> 1) & 7 IS the base code for
+    A, C, G, T and N, one look-up checks that nothing else is there, a wave that finds something else stages the tile
+    again with the exact form and stays with it.  (1) Clean rows padded with 'N' (what this package's producers write)
+    through the fast form ALONE -- CUTSEQ_FAST_RECODE=2 never falls back, so a green run proves the fast codes themselves;
+    (2) the same reads with zero padding, with garbage behind the reads, with IUPAC codes, lower case, '@', NUL and bytes
+    above 127 inside them: the check must send those tiles to the exact form (default mode), results == oracle either way;
+    (3) the aliases are real: 'B' reads as C and 'D' as T when the check is ignored, so mode 2 on dirty reads differs."""
+    st = planmod.CutadaptConfig()
+    st.trim_polyA = True
+    tp = util.compile_plan(BUILDIN_ADAPTERS["TAKARAV3"], st, True)
+    clean = synth.generate_pairs(20_000, read_len, seed=read_len, poly_fraction=0.1, art5_fraction=0.02)
+    assert (clean.seq1[:, read_len:] == ord("N")).all() and (clean.qual1[:, read_len:] == 0).all()
+    monkeypatch.setenv("CUTSEQ_FAST_RECODE", "2")
+    run_both(tp, clean)
+    monkeypatch.delenv("CUTSEQ_FAST_RECODE")
+    rng = np.random.default_rng(read_len)
+
+    def variant(kind):
+        b = SynthBatch(clean.seq1.copy(), clean.qual1.copy(), clean.len1.copy(), clean.seq2.copy(), clean.qual2.copy(), clean.len2.copy())
+        for seq, lens in ((b.seq1, b.len1), (b.seq2, b.len2)):
+            if kind == "zero padding":
+                seq[:, read_len:] = 0
+            elif kind == "garbage behind shorter reads":
+                cut = rng.random(b.n) < 0.3
+                lens[cut] = rng.integers(0, read_len, size=int(cut.sum())).astype(np.uint16)  # the bases behind stay: garbage
+            else:  # odd bytes inside a few reads: some tiles fall back, most do not
+                rows = np.flatnonzero(rng.random(b.n) < 0.01)
+                odd = np.frombuffer(b"RYKMSWBDHVnacgt@\x00\x80\xffU.-*", dtype=np.uint8)
+                for r in rows:
+                    for _ in range(int(rng.integers(1, 4))):
+                        seq[r, int(rng.integers(0, read_len))] = odd[int(rng.integers(0, odd.size))]
+        return b
+
+    for kind in ("zero padding", "garbage behind shorter reads", "odd bytes"):
+        for mode in ("1", "0"):
+            monkeypatch.setenv("CUTSEQ_FAST_RECODE", mode)
+            run_both(tp, variant(kind))
+        monkeypatch.delenv("CUTSEQ_FAST_RECODE")
+    # (3) an adapter copy whose C is written 'B' and whose T is written 'D': no match for the oracle and the checked forms,
+    # a match for the unchecked fast form
+    ad = "AGATCGGAAGAGCACACGTC"
+    bad_ad = ad.replace("C", "B", 1).replace("T", "D", 1)
+    reads = [(util.random_dna(random.Random(i), 60) + (bad_ad if i % 2 else ad) + "GGTTGGTTGG", None) for i in range(256)]
+    reads = [(s, "I" * len(s)) for s, _ in reads]
+    b = util.batch_from_reads(reads, reads)
+    b.seq1[b.seq1 == 0] = ord("N")
+    b.seq2[b.seq2 == 0] = ord("N")
+    tp1 = planmod.TrimPlan(r1=planmod.MateChain([planmod.back(ad, 0.0, 20, flag=abi.CS_F_ADAPTER3)]),
+                           r2=planmod.MateChain([planmod.back(ad, 0.0, 20, flag=abi.CS_F_ADAPTER3)]), has_umi=False, min_length=0,
+                           untrimmed_filter=False)
+    g1, _ = run_both(tp1, b)
+    assert ((g1["flags"] & abi.CS_F_ADAPTER3) != 0).tolist() == [i % 2 == 0 for i in range(256)]
+    monkeypatch.setenv("CUTSEQ_FAST_RECODE", "2")
+    with TrimEngine(tp1, device=0, slots=1, max_reads=b.n, max_stride=b.stride) as eng:
+        u1, _, _ = eng.trim(b.seq1, b.qual1, b.len1, b.seq2, b.qual2, b.len2)
+    assert ((u1["flags"] & abi.CS_F_ADAPTER3) != 0).all()  # unchecked, 'B' and 'D' pass for C and T: the check is not decoration
