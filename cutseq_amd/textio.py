@@ -180,7 +180,7 @@ class TextReader(threading.Thread):
     def _read_plain(self, fd: int, pos: int, buf: np.ndarray, fill: int, want: int):
         """``want`` bytes of the file from ``pos`` on, several preads (and newline counts) at once in the pool."""
         L = _host()
-        pieces = max(1, min(8, (want + _BLOCK - 1) // _BLOCK))
+        pieces = max(1, min(16, (want + _BLOCK - 1) // _BLOCK))  # (a block of 262 144 short-read records: 11 pieces, one round)
         want = pieces * _BLOCK
         buf = self._room(buf, fill, want)
         base = buf.ctypes.data
@@ -406,9 +406,7 @@ class _Shared:
 _libc = None
 
 
-def _fallocate(fd: int, offset: int, length: int) -> bool:
-    """Linux fallocate(2), mode 0 (extends the file) -> False when the file system has no such thing.  (Not
-    os.posix_fallocate: glibc emulates a missing fallocate by touching every block.)"""
+def _bind_libc():
     global _libc
     if _libc is None:
         try:
@@ -417,7 +415,13 @@ def _fallocate(fd: int, offset: int, length: int) -> bool:
             _libc.fallocate.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64]
         except (OSError, AttributeError):
             _libc = False
-    if not _libc:
+    return _libc
+
+
+def _fallocate(fd: int, offset: int, length: int) -> bool:
+    """Linux fallocate(2), mode 0 (extends the file) -> False when the file system has no such thing.  (Not
+    os.posix_fallocate: glibc emulates a missing fallocate by touching every block.)"""
+    if not _bind_libc():
         return False
     if _libc.fallocate(fd, 0, offset, length) == 0:
         return True
@@ -503,8 +507,11 @@ class StreamWriter:
     def _copy_mapped(self, mv: memoryview, n: int) -> None:
         start, end = self.pos, self.pos + n
         # the new range gets its pages in ONE call where the file system can do that (tmpfs, ext4, xfs: 18 GB/s on the
-        # GPU box against 4-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write.py).
-        # (Allocating the NEXT range in the pool meanwhile was tried: no faster, the call competes with the copies.)
+        # GPU box against 3-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write.py).
+        # Tried again in round 5 and dropped (profiles/r05_host_io.md): allocating the NEXT range meanwhile (fallocate and
+        # copies into another range of the same file slow each other down: 16 -> 8 GB/s for two files), and having every
+        # copy job map its piece first (madvise MADV_POPULATE_WRITE: +27 % for the writers alone, nothing inside the
+        # pipeline, where the same 16 threads also read).
         if not (self._can_allocate and _fallocate(self.fd, start, n)):
             self._can_allocate = False
             os.ftruncate(self.fd, end)

@@ -174,10 +174,9 @@ def main():
         out[tag] = {"seconds": round(dt, 3), "M_pairs_per_s": round(n / dt / 1e6, 2), "profile": prof[-1]["cutseq_profile"] if prof else None}
 
     run("full_cold")
-    run("full_warm_1")
-    run("full_warm_2")
+    for rep in range(3):
+        run(f"full_warm_{rep + 1}")
     run("discard_output", {"CUTSEQ_DISCARD_OUTPUT": "1"})
-    run("full_warm_3")
     shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(out))
 
