@@ -398,6 +398,9 @@ int launch(cs_engine *eng, hipStream_t stream, hipStream_t rstream, const cs_rea
     // scan kernel: 2x the resident set, late blocks even out the tail; resolve kernel: the resident set
     // pipelined resolve kernel: it runs beside the next call's scan kernel -- one wave per SIMD (its 128
     // VGPRs are what four scan waves leave free), the scan kernel keeps the rest of the machine
+    // (more resolve waves for the command line's small launches were tried in round 5 -- 8 per CU so that every batch of
+    // 16 records has a wave of its own: 122 -> 137 us, dropped: the kernel's duration there is one wave's chain of round
+    // trips, not the number of batches per wave)
     if (mode == csdev::MODE_RESOLVE && rstream != stream && per_cu > eng->knob_resolve_waves) per_cu = eng->knob_resolve_waves;
     uint32_t resident = (uint32_t)eng->n_cus * per_cu * (mode == csdev::MODE_SCAN ? 2u : 1u);
     gx[mode] = resident / mates;

@@ -626,6 +626,18 @@ def test_one_huge_gzip_member_decodes_in_parallel(tmp_path, monkeypatch):
     for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):  # fixed-code blocks are not what the finder looks for
         c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
         assert read(c.compress(body) + c.flush(), expect_parallel=False) == body
+    # what pigz writes (and this repo's tier inputs): ONE member made of pieces joined by sync flushes -- an empty stored
+    # block every 128 KB of text.  A chunk that ends in front of such a block goes on through it: the chunk behind starts
+    # at the dynamic block BEHIND the flush (round 5: a third of a pigz file's chunks fell back to the serial decoder)
+    def pieces(nbytes):
+        parts = []
+        for lo in range(0, len(body), nbytes):
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            parts.append(c.compress(body[lo:lo + nbytes]) + c.flush(zlib.Z_FINISH if lo + nbytes >= len(body) else zlib.Z_SYNC_FLUSH))
+        return (b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\xff" + b"".join(parts) + zlib.crc32(body).to_bytes(4, "little")
+                + (len(body) & 0xffffffff).to_bytes(4, "little"))
+    for nbytes in (128 << 10, 40_000, 1 << 20):
+        assert read(pieces(nbytes)) == body
     tail = b"@tail\nACGT\n+\nIIII\n"
     assert read(gzip.compress(body, 1) + gzip.compress(tail, 6)) == body + tail  # members behind the big one
     named = b"\x1f\x8b\x08\x08\0\0\0\0\0\xffreads.fq\0" + gzip.compress(body, 1)[10:]
