@@ -910,7 +910,11 @@ class FastaSource:
         self.inner.close()
 
     def blocks(self, start: int = 0) -> Iterator[tuple]:
-        carry = b""
+        # What goes to the converter always ENDS IN FRONT OF A RECORD START (a '>' at the start of a line): the record
+        # that is still open when a block ends waits in `pending`, piece by piece, and is converted once -- when the
+        # block with the next record start (or the end of the input) arrives.  (Round 4 prepended the open record to every
+        # new block and converted it again from its start: sixty passes over a 250 MB contig)
+        pending: list = []   # the open record's pieces (bytes)
         line0 = 0
         gen = self.inner.blocks(start)
         done = False
@@ -918,23 +922,29 @@ class FastaSource:
             item = next(gen, None)
             if item is None:
                 done = True
-                data = carry
+                data, pending = b"".join(pending), []
             else:
                 arr, nbytes = item
-                data = carry + bytes(memoryview(arr)[:nbytes])
+                block = bytes(memoryview(arr)[:nbytes])
                 self.give(arr)
-            if not data and done:
-                break
+                ends_line = (pending[-1][-1:] == b"\n") if pending else True
+                cut = block.rfind(b"\n>")
+                cut = cut + 1 if cut >= 0 else (0 if block[:1] == b">" and ends_line and pending else -1)
+                if cut < 0 or (cut == 0 and not pending):
+                    pending.append(block)  # no record starts in here (or only the block's first one): the record stays open
+                    continue
+                data, pending = b"".join(pending) + block[:cut], [block[cut:]]
+            if not data:
+                continue
             out = self.take(3 * len(data) + 64)
-            produced, consumed, err_line = self.convert(data, out, done)
+            produced, consumed, err_line = self.convert(data, out, True)
             if produced == -2:
                 self.give(out)
                 raise ValueError(f"{self.label}: FASTA format error in line {line0 + err_line}: expected '>' at the start of a record")
-            if produced < 0:
+            if produced < 0 or consumed != len(data):
                 self.give(out)
                 raise MemoryError("FASTA conversion buffer too small")
-            line0 += data[:consumed].count(b"\n")
-            carry = data[consumed:]
+            line0 += data.count(b"\n")
             if produced:
                 yield out, produced
             else:

@@ -156,8 +156,13 @@ def _first_id(path: str, offset: int) -> Optional[bytes]:
         text = zlib.decompressobj(31).decompress(raw, 1 << 14)
     except zlib.error:
         return None
-    line = text.split(b"\n", 1)[0]
+    lines = text.split(b"\n", 4)
+    line = lines[0]
     if not line.startswith(b"@"):
+        return None
+    # a quality line may start with '@' as well: where the member's first four lines are all there they must look like a
+    # record -- '+' line third, sequence and quality lines of one length (with one file there is no mate's id to compare)
+    if len(lines) == 5 and not (lines[2].startswith(b"+") and len(lines[1].rstrip(b"\r")) == len(lines[3].rstrip(b"\r"))):
         return None
     name = line[1:].split(b" ", 1)[0].split(b"\t", 1)[0]
     return name[:-1] if name[-1:] in (b"1", b"2", b"3") else name
@@ -312,6 +317,11 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
         try:
             return _run_ranks(argv, args, world, shares, t0, "gzip members (nothing inflated twice)")
         except RankFailure as exc:
+            # only a rank that found its share's records out of step (exit code RANK_EXIT_RECORDS: FASTQ format / pairing
+            # errors) says anything about the split; a full disk, a GPU error or a missing file would fail the same way
+            # again, twice as late
+            if exc.code != RANK_EXIT_RECORDS:
+                raise
             logging.warning(f"--ranks {world}: the split by gzip members did not hold ({exc}); once more with the exact split.")
     shares, info = split_inputs(paths, world)
     if shares is None:
@@ -320,8 +330,13 @@ def run_parent(argv: List[str], args, tp) -> Optional[dict]:
     return _run_ranks(argv, args, world, shares, t0, f"record indices from a counting pass ({why})")
 
 
+RANK_EXIT_RECORDS = 3  # a rank's exit code for "my share's records do not line up" (run.run_cutseq)
+
+
 class RankFailure(RuntimeError):
-    pass
+    def __init__(self, message: str, code: int = 1):
+        super().__init__(message)
+        self.code = code
 
 
 def _run_ranks(argv: List[str], args, world: int, shares, t0: float, how: str) -> dict:
@@ -365,7 +380,7 @@ def _run_ranks(argv: List[str], args, world: int, shares, t0: float, how: str) -
                     continue
                 left.remove(r)
                 if code != 0:
-                    raise RankFailure(f"rank {r} failed (exit code {code})")
+                    raise RankFailure(f"rank {r} failed (exit code {code})", code)
             if left:
                 time.sleep(0.01)
         for key, names in groups.items():

@@ -507,7 +507,16 @@ def run_cutseq(args, argv=None):
                 args.demux_files[int(key.split(":")[1])] = names
             else:
                 setattr(args, key, names)
-        totals = run_pipeline(args, tp, shares=spec["inputs"])
+        try:
+            totals = run_pipeline(args, tp, shares=spec["inputs"])
+        except (ValueError, OSError) as exc:
+            from . import fastq
+            # records out of step in THIS share (malformed record, mate ids that differ, unequal record counts): the one
+            # failure that tells the parent its split by gzip members did not hold (ranks.RANK_EXIT_RECORDS)
+            if isinstance(exc, fastq.FastqFormatError) or "IDs not identical" in str(exc) or "improperly paired" in str(exc):
+                logging.error(str(exc))
+                sys.exit(ranks.RANK_EXIT_RECORDS)
+            raise
         ranks.dump_totals(spec, totals)
         return totals
     if getattr(args, "ranks", 1) > 1:
@@ -583,6 +592,10 @@ def main(argv: Optional[List[str]] = None):
         run_cutseq(args, argv)
     except (ReadTooLong, FileNotFoundError) as exc:  # user errors: the reference's exit style (run.py:1035-1039)
         _fail(str(exc))
+    except RuntimeError as exc:
+        if type(exc).__name__ != "RankFailure":
+            raise
+        _fail(f"{exc} -- its own message is above")  # (--ranks: the rank has already said what went wrong)
 
 
 def console_main():

@@ -1065,3 +1065,35 @@ def test_a_ranks_share_ends_at_its_member_even_through_the_zlib_fallback(tmp_pat
             src = codec.GzipSource(str(path), pool)
             assert b"".join(bytes(memoryview(arr)[:n]) for arr, n in src.blocks()) == a + b  # ... and nothing lost
             src.close()
+
+
+def test_fasta_record_longer_than_many_blocks_is_converted_once(tmp_path):
+    """FastaSource kept the open record in a carry and converted it again from its start with every new
+    4 MB block -- quadratic in the record's length.  Now the open record's pieces wait until the block with the next
+    record start arrives.  A 40 MB contig between short records: same text as the straight-line conversion, and the
+    converter sees every input byte once."""
+    from cutseq_amd import codec, textio
+    rng = np.random.default_rng(5)
+    contig = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=40 << 20).tobytes()
+    lines = b"\n".join(contig[i:i + 70] for i in range(0, len(contig), 70))
+    text = b">a first\nACGT\nAC\n>big one\n" + lines + b"\n>c\nGGGG\n>d\nTT"
+    want = b"@a first\nACGTAC\n+\n~~~~~~\n@big one\n" + contig + b"\n+\n" + b"~" * len(contig) + b"\n@c\nGGGG\n+\n~~~~\n@d\nTT\n+\n~~\n"
+    seen = []
+
+    def convert(data, out, final):
+        seen.append(len(data))
+        return textio.TextReader._fasta_convert(data, out, final)
+
+    class Inner:  # blocks of 1 MB, one of them starting exactly with a record's '>'
+        def blocks(self, start=0):
+            cuts = sorted({0, len(text)} | set(range(1 << 20, len(text), 1 << 20)) | {text.index(b">c")})
+            for lo, hi in zip(cuts, cuts[1:]):
+                yield np.frombuffer(text[lo:hi], dtype=np.uint8), hi - lo
+
+        def close(self):
+            pass
+
+    src = codec.FastaSource(Inner(), convert, lambda n: np.empty(n, dtype=np.uint8), lambda a: None, "t.fa")
+    got = b"".join(bytes(memoryview(arr)[:n]) for arr, n in src.blocks())
+    assert got == want
+    assert sum(seen) == len(text), (sum(seen), len(text))  # every byte converted once (round 4: ~20 times the contig)

@@ -152,8 +152,10 @@ def main():
                             "GBps": round(sum(os.path.getsize(p) for p in ins) / dt / 1e9, 2)}
     outs = ["-o", str(work / "o1.fastq"), str(work / "o2.fastq"), "-s", str(work / "s1.fastq"), str(work / "s2.fastq")]
 
-    def run(tag, env=None):
-        for f in list(work.glob("o[12].fastq")) + list(work.glob("s[12].fastq")):
+    gz_outs = ["-o", str(work / "o1.fastq.gz"), str(work / "o2.fastq.gz"), "-s", str(work / "s1.fastq.gz"), str(work / "s2.fastq.gz")]
+
+    def run(tag, env=None, outs=outs):
+        for f in list(work.glob("o[12].fastq*")) + list(work.glob("s[12].fastq*")):
             f.unlink()
         for k, v in (env or {}).items():
             os.environ[k] = v
@@ -177,6 +179,8 @@ def main():
     for rep in range(3):
         run(f"full_warm_{rep + 1}")
     run("discard_output", {"CUTSEQ_DISCARD_OUTPUT": "1"})
+    for rep in range(3):
+        run(f"plain_to_gz_{rep + 1}", outs=gz_outs)
     shutil.rmtree(work, ignore_errors=True)
     print(json.dumps(out))
 
