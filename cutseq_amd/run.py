@@ -601,7 +601,7 @@ def main(argv: Optional[List[str]] = None):
 def console_main():
     """Entry point of the ``cutseq`` console script and of ``python -m cutseq_amd.run``.  When the run is over the
     process ends at once: unwinding the HIP runtime, its streams and gigabytes of page-locked memory takes longer than
-    a short run itself (tools/startup_probe.py), and the operating system reclaims all of it anyway.  Tools that
+    a short run itself (profiles/HISTORY.md), and the operating system reclaims all of it anyway.  Tools that
     collect their data when the process exits normally (rocprofv3 and friends preload a library) get the normal
     exit; so does anybody who sets CUTSEQ_FAST_EXIT=0."""
     traced = any("rocprof" in os.environ.get(k, "").lower() or "roctracer" in os.environ.get(k, "").lower()

@@ -507,7 +507,7 @@ class StreamWriter:
     def _copy_mapped(self, mv: memoryview, n: int) -> None:
         start, end = self.pos, self.pos + n
         # the new range gets its pages in ONE call where the file system can do that (tmpfs, ext4, xfs: 18 GB/s on the
-        # GPU box against 3-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write.py).
+        # GPU box against 3-6 GB/s when the copies below fault them in one by one; tools/micro/tmpfs_write2.py).
         # Tried again in round 5 and dropped (profiles/r05_host_io.md): allocating the NEXT range meanwhile (fallocate and
         # copies into another range of the same file slow each other down: 16 -> 8 GB/s for two files), and having every
         # copy job map its piece first (madvise MADV_POPULATE_WRITE: +27 % for the writers alone, nothing inside the
