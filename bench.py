@@ -152,6 +152,14 @@ def self_launch(n_ranks: int) -> int:
     return code
 
 
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(map(str, v)) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as exc:  # (a local query: it must never take the N-rank line down)
+        return f"unknown ({type(exc).__name__})"
+
+
 def device_identity(index: int) -> dict:
     """Name, uuid and PCI bus id of the device a rank runs on (two ranks on one device must be visible in the line)."""
     out = {"index": index, "pid": os.getpid()}
@@ -205,7 +213,8 @@ def main():
     # legs need (baseline sample, parity sample, tier data) -- and that head is compared with the device's bytes.
     # config 5 plants its barcodes with numpy: it keeps the host generator, in pieces.
     tiers_on = args.tier_pairs > 0 and args.workload == "config3" and world == 1
-    keep = min(n, max(args.cpu_sample, PARITY_SAMPLE, args.tier_pairs if tiers_on else 0))
+    keep = min(n, max(args.cpu_sample if world == 1 else 0, PARITY_SAMPLE, args.tier_pairs if tiers_on else 0))
+    host_threads = max(1, synth.usable_cpus() // world)  # (the ranks share the host: the head of N shards at once)
     names = ("seq1", "qual1", "len1") + (("seq2", "qual2", "len2") if paired else ())
     stride = synth._stride_for(READ_LEN)
     d = {name: torch.empty((n,) if name.startswith("len") else (n, stride),
@@ -215,7 +224,7 @@ def main():
         batch = None
         for at in range(0, n, GEN_PIECE):
             m = min(GEN_PIECE, n - at)
-            piece = workloads.make_batch(args.workload, m, first_index=first + at)
+            piece = workloads.make_batch(args.workload, m, first_index=first + at, threads=host_threads)
             assert piece.stride == stride
             for name in names:
                 arr = getattr(piece, name)
@@ -230,7 +239,7 @@ def main():
     else:
         ptrs = [d[name].data_ptr() for name in names] + [None] * (6 - len(names))
         assert workloads.fill_device(args.workload, n, ptrs, first_index=first) == stride
-        batch = workloads.make_batch(args.workload, keep, first_index=first)  # the generator the parity tests use
+        batch = workloads.make_batch(args.workload, keep, first_index=first, threads=host_threads)  # the generator the parity tests use
         torch.cuda.synchronize(dev)
         head_equal = all(bool(torch.equal(d[name][:keep].cpu(), torch.from_numpy(
             getattr(batch, name).view(np.int16) if name.startswith("len") else getattr(batch, name)))) for name in names)
@@ -307,7 +316,7 @@ def main():
             "devices": ident,                                      # name / uuid / PCI bus id each rank ran on
             "distinct_devices": len({(i or {}).get("uuid") or (i or {}).get("pci_bus_id") or k for k, i in enumerate(ident)}),
             "rccl_world": dist.get_world_size(), "backend": dist.get_backend(),
-            "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if not rehearsal else None,
+            "rccl_version": None if rehearsal else rccl_version(),
         }
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

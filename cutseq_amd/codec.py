@@ -437,10 +437,14 @@ class GzipSource:
                 for p in cands:
                     submit(p)
                 rc, used, out, produced = tasks.pop(head).result()
-                if rc == 3 and cap[0] < _MEMBER_CAP and any(head < p <= head + _MEMBER_CAP // 4 for p in cands):
-                    # bigger than the members seen so far, and another member seems to start not far behind it: once
-                    # more with the largest buffer.  (No member magic within 64 MB of compressed bytes: one huge member,
-                    # the usual sequencer output -- not worth inflating a quarter of a gigabyte to find that out.)
+                if rc == 3 and cap[0] < _MEMBER_CAP and any(
+                        tasks[p].result()[0] in (0, 3) for p in cands if head < p <= head + _MEMBER_CAP // 4 and p in tasks):
+                    # bigger than the members seen so far, and another member DOES start not far behind it (its own
+                    # inflate got somewhere: the bytes 1f 8b 08 turn up by chance a couple of dozen times per gigabyte of
+                    # compressed data, and such a place fails in its header or a few blocks in -- round 5: one of them
+                    # within 64 MB of a huge member's start cost the run a quarter of a gigabyte of pointless inflate,
+                    # 0.2 s of a 0.4 s run): once more with the largest buffer.  (No member anywhere near: one huge member,
+                    # the usual sequencer output.)
                     cap[0] = _MEMBER_CAP
                     rc, used, out, produced = self._inflate_member_at(head, _MEMBER_CAP, False)
                 if rc == 3:  # one very large member: its chunks decode in parallel (csrc/pinflate.c), or zlib streams it
@@ -616,6 +620,9 @@ class GzipSource:
                 self.stats["chunks"] = self.stats.get("chunks", 0) + 1
                 if start != pos or rc != 0:
                     self.stats["serial"] = self.stats.get("serial", 0) + 1
+                    if os.environ.get("CUTSEQ_DEBUG_INFLATE") == "1":  # diagnostic: which chunk lost its proof, and how
+                        import sys
+                        print(f"inflate: chunk {i} of {n_chunks} (S = {S}): proven bit {pos}, speculative start {start}, rc {rc}", file=sys.stderr)
                     # not proven (finder missed the boundary, saw a false one, or the chunk overflowed): from the proven
                     # position, serially
                     if raw is not None:

@@ -333,3 +333,51 @@ def test_text_path_demultiplexes_into_one_route_per_barcode(compress, paired, le
             assert int(res.route_count[0]) == sum(want_counts[3:]) and int(res.route_count[1]) == want_counts[1]
             out = [np.empty(max(int(res.out_bytes[m]), 1), dtype=np.uint8) for m in range(2)]
             te.fetch(1, out[0], out[1] if paired else None)
+
+
+@pytest.mark.parametrize("style", ["every byte value", "fibonacci frequencies", "two symbols"])
+def test_device_gzip_code_construction_at_its_edges(style):
+    """The device's Huffman construction (deflate_kernels.hip.inc, huff_build: the whole block builds the code -- compaction
+    by a scan, rank sort, two-queue merge, length limit on the histogram, canonical codes from per-wave ballots) away from
+    FASTQ's few dozen symbols: quality lines that use every byte value but the line ends (more than 256 used literal /
+    length symbols: both symbols of a thread), frequencies that grow like Fibonacci numbers (an unlimited code would be
+    twenty bits deep: the 15-bit limit is enforced), and a text of two symbols (codes of one bit).  Any inflater must
+    give back the uncompressed form's bytes."""
+    import gzip
+    import random
+    rng = random.Random(31)
+    scheme = "ACACGACGCTCTTCCGATCT>AGATCGGAAGAGCACACGTC"
+    st = planmod.CutadaptConfig()
+    st.min_length = 0
+    st.min_quality = -1000  # nothing is quality-trimmed, whatever the bytes say
+    tp = util.compile_plan(scheme, st, False)
+    n, L = 4000, 148
+    if style == "every byte value":
+        alphabet = [b for b in range(1, 256) if b not in (10, 13)]
+        weights = [1] * len(alphabet)
+    elif style == "fibonacci frequencies":
+        alphabet = list(range(40, 40 + 22))
+        weights = [1, 1]
+        while len(weights) < len(alphabet):
+            weights.append(weights[-1] + weights[-2])
+    else:
+        alphabet, weights = [ord("I")], [1]
+    seq = np.full((n, 152), ord("A") if style == "two symbols" else 0, dtype=np.uint8)
+    qual = np.zeros((n, 152), dtype=np.uint8)
+    for i in range(n):
+        if style != "two symbols":
+            seq[i, :L] = np.frombuffer(bytes(rng.choices(b"ACGT", k=L)), dtype=np.uint8)
+        qual[i, :L] = np.frombuffer(bytes(rng.choices(alphabet, weights=weights, k=L)), dtype=np.uint8)
+    lens = np.full(n, L, dtype=np.uint16)
+    names = [b"A" if style == "two symbols" else b"q%d" % i for i in range(n)]
+    text = fastq_text(names, seq, qual, lens)
+    plain, counts = run_text(tp, text, None, n, 152)
+    with TrimEngine(tp, device=0, slots=0) as eng:
+        with textpath.TextEngine(eng, slots=1, max_text_bytes=len(text) + 1024, max_records=n, stride=152, compress=True) as te:
+            packed, counts2 = te.run(text, n, None)
+    assert counts2 == counts and sum(counts) == n
+    for route in range(3):
+        if plain[route][0]:
+            assert gzip.decompress(packed[route][0]) == plain[route][0], (style, route)
+    if style == "fibonacci frequencies":
+        assert len(packed[0][0]) < 0.8 * len(plain[0][0])  # (a limited code still compresses a skewed source)

@@ -1097,3 +1097,34 @@ def test_fasta_record_longer_than_many_blocks_is_converted_once(tmp_path):
     got = b"".join(bytes(memoryview(arr)[:n]) for arr, n in src.blocks())
     assert got == want
     assert sum(seen) == len(text), (sum(seen), len(text))  # every byte converted once (round 4: ~20 times the contig)
+
+
+def test_a_chance_member_magic_near_a_huge_member_costs_no_second_inflate(tmp_path, monkeypatch):
+    """Round 5: the bytes 1f 8b 08 turn up by chance in compressed data; one of them within reach of a huge member's start
+    used to count as "another member starts not far behind it" and the whole member was inflated once more into the
+    largest buffer before the parallel decoder got it (0.2 s of a 0.4 s run).  A candidate only counts when its own
+    inflate got somewhere.  Here the false magic sits in the header's file-name field."""
+    from cutseq_amd import codec
+    body = b"@r\nACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIII\n" * 900_000  # 45 MB: beyond the first trial's 32 MB
+    raw = gzip.compress(body, 1)
+    blob = b"\x1f\x8b\x08\x08\0\0\0\0\0\xff" + b"a\x1f\x8b\x08\x01b.fq\0" + raw[10:]
+    path = tmp_path / "big.fq.gz"
+    path.write_bytes(blob)
+    monkeypatch.setattr(codec, "_MEMBER_CAP", 40 << 20)  # the member does not fit the largest buffer either
+    calls = []
+    real = codec.GzipSource._inflate_member_at
+
+    def spy(self, pos, cap, grow):
+        calls.append((pos, cap))
+        return real(self, pos, cap, grow)
+
+    monkeypatch.setattr(codec.GzipSource, "_inflate_member_at", spy)
+    src = codec.GzipSource(str(path), fastq._pool())
+    got = 0
+    for b, n in src.blocks():
+        assert bytes(memoryview(b)[:n]) == body[got:got + n]
+        got += n
+    src.close()
+    assert got == len(body)
+    assert any(pos == 11 for pos, _ in calls), calls               # the false candidate was tried ...
+    assert [c for c in calls if c[0] == 0] == [(0, 32 << 20)], calls  # ... and the member itself was tried ONCE, at 32 MB

@@ -37,7 +37,8 @@ def member(piece_records):
     return b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\xff" + b"".join(parts) + int(crc).to_bytes(4, "little") + int(len(flat) & 0xffffffff).to_bytes(4, "little")
 
 
-for label, pr in (("one stream", n), ("pieces of 262144", 262144), ("pieces of 65536", 65536), ("pieces of 4096", 4096), ("pieces of 400 (pigz: 128 KB)", 400)):
+os.environ["CUTSEQ_DEBUG_INFLATE"] = "1"
+for label, pr in (("one stream", n), ("pieces of 1048576", 1 << 20), ("pieces of 262144", 262144), ("pieces of 65536", 65536), ("pieces of 4096", 4096), ("pieces of 400 (pigz: 128 KB)", 400)):
     path = work / "m.fastq.gz"
     path.write_bytes(member(pr))
     for rep in range(2):
@@ -51,5 +52,6 @@ for label, pr in (("one stream", n), ("pieces of 262144", 262144), ("pieces of 6
         stats = dict(src.stats)
         src.close()
         assert got == len(flat)
-    print(f"{label:32s} {os.path.getsize(path) / 1e6:8.1f} MB  {got / dt / 1e9:6.2f} GB/s of text   chunks {stats.get('chunks')} serial {stats.get('serial', 0)}")
+    print(f"{label:32s} {os.path.getsize(path) / 1e6:8.1f} MB  {got / dt / 1e9:6.2f} GB/s of text   chunks {stats.get('chunks')} serial {stats.get('serial', 0)}  "
+          + " ".join(f"{k} {v:.2f}" for k, v in sorted(stats.items()) if k.endswith("_s")), flush=True)
     path.unlink()

@@ -105,13 +105,13 @@ def names_of(n: int, mate: int, first: int = 0):
     return [f"SIM:{first + i:0{ID_DIGITS}d} {mate}:N:0:IDX".encode() for i in range(n)]
 
 
-def write_inputs(work: Path, batch, n: int, pool: ThreadPoolExecutor):
+def write_inputs(work: Path, batch, n: int, pool: ThreadPoolExecutor, piece_records: int = 262_144):
     """plain_R{1,2}.fastq, multi_R{1,2}.fastq.gz (one member per 65 536 records), single_R{1,2}.fastq.gz (ONE member:
     raw-deflate pieces of 262 144 records joined by sync flushes, the way pigz builds one; level 1, zlib's deflate_fast
     like gzip -1).  A job of the pool is 262 144 records of one mate: their text, their four members, their raw piece
     (numpy copies and zlib both run outside the interpreter lock) -- assembling 2.6 GB of text on one thread and
     compressing one 1.3 GB piece per mate used to be half of bench.py's wall time."""
-    MEMBER, PIECE = 65_536, 262_144
+    MEMBER, PIECE = 65_536, piece_records
 
     def job(args):
         mate, lo, hi, last = args
