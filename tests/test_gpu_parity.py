@@ -215,6 +215,40 @@ def test_leading_adapter_pair_in_one_walk(rule, anywhere, monkeypatch):
         assert np.array_equal(g_pair, g_apart)
 
 
+@pytest.mark.parametrize("m", [8, 9, 16, 17, 24, 25, 31, 32])
+def test_end_rows_four_per_step_and_the_tail_group(m):
+    """Round 5's two rewrites in the leading walk, swept instead of sampled: (a) which rows of the last column are
+    acceptable comes from four rows per step -- byte b of a dword walks rows 8 b + 1 .. 8 b + 8 -- so the adapter
+    lengths sit on both sides of every byte boundary, min_overlap moves the first tested row, and the reads end in
+    EVERY prefix length of the adapter with 0 / 1 / 2 errors (and one base more or less: the neighbouring rows);
+    (b) the columns behind a read's last whole group of eight run as one masked group whose scores are logged, so the
+    read lengths cover every remainder mod 8 (and reads shorter than one group).  A 3' adapter alone (the walk
+    without the 5' test) and the reference's pair (RightmostFrontAdapter in front of it); both selection rules."""
+    rng = random.Random(4200 + m)
+    p3 = util.random_dna(rng, m, "ACGT")
+    p5 = util.random_dna(rng, 12, "ACGT")
+    reads = []
+    for overlap in range(0, m + 1):
+        for errs in (0, 1, 2):
+            for body_len in (0, 1, 5, 17, 40, 41, 42, 43, 44, 45, 46, 47):
+                tail = util.mutate(rng, p3[:overlap], errs, "ACGT") if overlap else ""
+                s = util.random_dna(rng, body_len, "ACGT") + tail
+                reads.append((s, "I" * len(s)))
+                if overlap and rng.random() < 0.3:  # the whole adapter further in, and a partial one at the end
+                    s2 = util.random_dna(rng, 9, "ACGT") + util.mutate(rng, p3, errs, "ACGT") + util.random_dna(rng, body_len % 7, "ACGT") + tail
+                    reads.append((s2, "I" * len(s2)))
+    batch = util.batch_from_reads(reads)
+    for rate, mo in ((0.1, 3), (0.2, 1), (0.2, 3), (0.34, min(9, m)), (0.2, m)):
+        for rule in (0, 1):
+            run_both(one_adapter_plan(p3, rate, mo, WHERE["BACK"], abi.CS_REMOVE_AFTER, rule=rule), batch, threads=8)
+        ops = [planmod.AdapterOp("p5", p5[::-1], 0.2, 6, WHERE["BACK"], abi.CS_REMOVE_BEFORE, rightmost=True,
+                                 match_flag=abi.CS_F_ADAPTER5),
+               planmod.AdapterOp("p3", p3, rate, mo, WHERE["BACK"], abi.CS_REMOVE_AFTER, match_flag=abi.CS_F_ADAPTER3)]
+        tp = planmod.TrimPlan(r1=planmod.MateChain(ops), r2=None, has_umi=False, min_length=0, untrimmed_filter=False,
+                              select_rule=0, use_filter=True, indel_tie=abi.CS_TIE_INSERTION)
+        run_both(tp, batch, threads=8)
+
+
 @pytest.mark.parametrize("slots", ["", "1", "3"])
 @pytest.mark.parametrize("solo", [False, True])
 def test_item_log_of_the_leading_walk_overflows_into_the_queue(solo, slots, monkeypatch):
